@@ -1,0 +1,94 @@
+"""ctypes binding of libica_hip.so (include/ica_hip.h).  There is no fallback: if the HIP library is
+missing the import of the compute path fails loudly."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+ICA_MAX_SCALES = 16
+ICA_TRACE_STRIDE = 10
+ICA_FLAG_EXACT_UPDATE = 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libica_hip.so")
+
+
+class IcaError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"libica_hip status {status}: {message}")
+        self.status = status
+
+
+class Problem(C.Structure):
+    _fields_ = [("batch", C.c_int32), ("height", C.c_int32), ("width", C.c_int32), ("channels", C.c_int32),
+                ("transform_type", C.c_int32), ("robust_type", C.c_int32), ("nscales", C.c_int32),
+                ("max_iter", C.c_int32), ("nanifoutside", C.c_int32), ("delta", C.c_int32), ("flags", C.c_int32),
+                ("reserved", C.c_int32), ("tol", C.c_double), ("lambda_", C.c_double), ("nu", C.c_double),
+                ("lambda0", C.c_double), ("lambdaN", C.c_double), ("lambda_ratio", C.c_double)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("pair_iterations", C.c_int64 * ICA_MAX_SCALES), ("pair_iterations_total", C.c_int64),
+                ("iter_launches", C.c_int64 * ICA_MAX_SCALES), ("iter_kernel_ms", C.c_double * ICA_MAX_SCALES),
+                ("iter_kernel_bytes", C.c_double * ICA_MAX_SCALES), ("level_width", C.c_int32 * ICA_MAX_SCALES),
+                ("level_height", C.c_int32 * ICA_MAX_SCALES)]
+
+
+_P = C.c_void_p
+_SIGNATURES = {
+    "ica_version": (C.c_int, []),
+    "ica_device_count": (C.c_int, []),
+    "ica_strerror": (C.c_char_p, [C.c_int]),
+    "ica_last_error": (C.c_char_p, [_P]),
+    "ica_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "ica_destroy": (C.c_int, [_P]),
+    "ica_set_stream": (C.c_int, [_P, _P]),
+    "ica_synchronize": (C.c_int, [_P]),
+    "ica_set_profiling": (C.c_int, [_P, C.c_int]),
+    "ica_nparams": (C.c_int, [C.c_int]),
+    "ica_zoom_size": (C.c_int, [C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ica_prepare": (C.c_int, [_P, C.POINTER(Problem)]),
+    "ica_solve_batch_dev": (C.c_int, [_P, C.POINTER(Problem), _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(Stats)]),
+    "ica_solve_batch": (C.c_int, [_P, C.POINTER(Problem), _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(Stats)]),
+    "ica_op_warp_dev": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
+    "ica_op_minmax_dev": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "ica_op_normal_equations_dev": (C.c_int, [_P, C.POINTER(Problem), _P, _P, _P, _P, _P, _P]),
+    "ica_op_solve_update_dev": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
+    "ica_op_pyramid_down_dev": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _P, _P]),
+    "ica_op_zoom_in_parameters_dev": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """dlopen libica_hip.so and declare every entry point of include/ica_hip.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built (python -m "
+            "inverse_compositional_algorithm_amd.build, or __graft_entry__.build()). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ica_version() != 1:
+        raise RuntimeError("libica_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(status: int, ctx=None) -> None:
+    if status == 0:
+        return
+    lib = load()
+    msg = lib.ica_strerror(status).decode()
+    if ctx is not None:
+        extra = lib.ica_last_error(ctx).decode()
+        if extra:
+            msg += f" ({extra})"
+    raise IcaError(status, msg)

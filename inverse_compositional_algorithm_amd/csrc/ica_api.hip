@@ -1,0 +1,644 @@
+// C ABI of libica_hip.so (include/ica_hip.h): context, workspaces, the pyramid / level / iteration
+// driver and the per-operator hooks.  Everything here is host code that enqueues the kernels of
+// ica_kernels.hpp on the context's stream; there is no CPU compute path.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/ica_hip.h"
+#include "ica_kernels.hpp"
+#include "ica_pyramid.hpp"
+
+using namespace ica;
+
+namespace {
+
+struct DevBuf {
+  void* ptr = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+    hipError_t e = hipMalloc(&ptr, bytes);
+    if (e == hipSuccess) cap = bytes;
+    return e;
+  }
+  void release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+  }
+  template <class T> T* as() const { return reinterpret_cast<T*>(ptr); }
+};
+
+struct DeviceBandOp {
+  DevBuf start, w;
+  int n_in = 0, n_out = 0, K = 0;
+  BandOp view() const { return BandOp{start.as<int>(), w.as<double>(), n_in, n_out, K}; }
+};
+
+struct LevelGeom {
+  int W = 0, H = 0;
+  int tiles_x = 0, tiles_y = 0, tile_h = 0, tiles = 0;
+};
+
+}  // namespace
+
+struct ica_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool profiling = false;
+  int poll_every = 3;
+  std::string last_error;
+  // workspaces
+  DevBuf pyr1[ICA_MAX_SCALES], pyr2[ICA_MAX_SCALES];  // levels >= 1
+  DevBuf tmp_resample;                                // intermediate of the separable pyramid pass
+  DevBuf partials, hinv, p_prev, lambda_it, error, niter, lists, counts, count_hist, minmax, mm_part, mm_in;
+  DevBuf scratch_p;
+  int* pinned_count = nullptr;
+  std::map<std::pair<int, int>, DeviceBandOp*> ops;
+  std::vector<hipEvent_t> ev_pool;
+  ~ica_ctx() {
+    for (auto& kv : ops) {
+      kv.second->start.release();
+      kv.second->w.release();
+      delete kv.second;
+    }
+    for (auto e : ev_pool) (void)hipEventDestroy(e);
+    for (int i = 0; i < ICA_MAX_SCALES; ++i) { pyr1[i].release(); pyr2[i].release(); }
+    DevBuf* all[] = {&tmp_resample, &partials, &hinv, &p_prev, &lambda_it, &error, &niter, &lists, &counts,
+                     &count_hist, &minmax, &mm_part, &mm_in, &scratch_p};
+    for (auto* b : all) b->release();
+    if (pinned_count) (void)hipHostFree(pinned_count);
+  }
+};
+
+namespace {
+
+#define ICA_HIP(ctx, expr)                                                                 \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) {                                                                \
+      (ctx)->last_error = std::string(#expr) + ": " + hipGetErrorString(_e);               \
+      return _e == hipErrorOutOfMemory ? ICA_ENOMEM : ICA_EHIP;                            \
+    }                                                                                      \
+  } while (0)
+
+#define ICA_TRY(expr)              \
+  do {                             \
+    int _s = (expr);               \
+    if (_s != ICA_OK) return _s;   \
+  } while (0)
+
+int validate(const ica_problem* pr) {
+  if (!pr) return ICA_EINVAL_ARG;
+  if (pr->channels != 1 && pr->channels != 3) return ICA_EINVAL_SHAPE;
+  if (pr->batch <= 0 || pr->height <= 0 || pr->width <= 0) return ICA_EINVAL_ARG;
+  if (!(pr->tol < 0.01)) return ICA_EINVAL_TOL;  // ref :59-60
+  if (nparams_of(pr->transform_type) < 0) return ICA_EINVAL_TRANSFORM;
+  if (pr->robust_type < ICA_QUADRATIC || pr->robust_type > ICA_CHARBONNIER) return ICA_EINVAL_ROBUST;
+  if (pr->nscales < 1 || pr->nscales > ICA_MAX_SCALES) return ICA_EINVAL_ARG;
+  if (pr->max_iter < 0 || pr->max_iter > 100000) return ICA_EINVAL_ARG;
+  return ICA_OK;
+}
+
+void level_sizes(const ica_problem* pr, LevelGeom* g) {
+  g[0].W = pr->width;
+  g[0].H = pr->height;
+  for (int s = 1; s < pr->nscales; ++s) {  // zoom.py:8-22
+    g[s].W = std::max(1, round_half_even(g[s - 1].W * pr->nu));
+    g[s].H = std::max(1, round_half_even(g[s - 1].H * pr->nu));
+  }
+  for (int s = 0; s < pr->nscales; ++s) {
+    g[s].tiles_x = (g[s].W + kTileW - 1) / kTileW;
+    // the tallest tile that still leaves >= ~8 workgroups per CU; taller tiles amortise the reduction
+    int th = 256;
+    while (th > 32) {
+      const long blocks = (long)pr->batch * g[s].tiles_x * ((g[s].H + th - 1) / th);
+      if (blocks >= 2048 && th <= std::max(32, g[s].H)) break;
+      th >>= 1;
+    }
+    g[s].tile_h = th;
+    g[s].tiles_y = (g[s].H + th - 1) / th;
+    g[s].tiles = g[s].tiles_x * g[s].tiles_y;
+  }
+}
+
+int get_op(ica_ctx* ctx, int n_in, int n_out, DeviceBandOp** out) {
+  auto key = std::make_pair(n_in, n_out);
+  auto it = ctx->ops.find(key);
+  if (it != ctx->ops.end()) {
+    *out = it->second;
+    return ICA_OK;
+  }
+  HostBandOp h = build_rescale_op(n_in, n_out);
+  auto* d = new DeviceBandOp();
+  d->n_in = n_in;
+  d->n_out = n_out;
+  d->K = h.K;
+  hipError_t e = d->start.ensure(h.start.size() * sizeof(int));
+  if (e == hipSuccess) e = d->w.ensure(h.w.size() * sizeof(double));
+  if (e == hipSuccess) e = hipMemcpy(d->start.ptr, h.start.data(), h.start.size() * sizeof(int), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d->w.ptr, h.w.data(), h.w.size() * sizeof(double), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    ctx->last_error = std::string("pyramid operator upload: ") + hipGetErrorString(e);
+    d->start.release();
+    d->w.release();
+    delete d;
+    return e == hipErrorOutOfMemory ? ICA_ENOMEM : ICA_EHIP;
+  }
+  ctx->ops[key] = d;
+  *out = d;
+  return ICA_OK;
+}
+
+int launch_minmax(ica_ctx* ctx, int batch, size_t elems, const float* img, float* out) {
+  int chunks = (int)std::min<size_t>(64, (elems + (size_t)kBlock * 16 - 1) / ((size_t)kBlock * 16));
+  chunks = std::max(chunks, 1);
+  ICA_HIP(ctx, ctx->mm_part.ensure((size_t)batch * chunks * 2 * sizeof(float)));
+  hipLaunchKernelGGL(ica_minmax_partial_kernel, dim3(chunks, batch), dim3(kBlock), 0, ctx->stream, img, elems, chunks,
+                     ctx->mm_part.as<float>());
+  hipLaunchKernelGGL(ica_minmax_final_kernel, dim3((batch + 255) / 256), dim3(256), 0, ctx->stream,
+                     ctx->mm_part.as<float>(), chunks, batch, out);
+  ICA_HIP(ctx, hipGetLastError());
+  return ICA_OK;
+}
+
+int launch_pyramid_down(ica_ctx* ctx, int batch, int C, int H, int W, int h, int w, const float* in, float* out) {
+  DeviceBandOp *ox = nullptr, *oy = nullptr;
+  ICA_TRY(get_op(ctx, W, w, &ox));
+  ICA_TRY(get_op(ctx, H, h, &oy));
+  const int planes = batch * C;
+  ICA_HIP(ctx, ctx->tmp_resample.ensure((size_t)planes * H * w * sizeof(float)));
+  ICA_HIP(ctx, ctx->mm_in.ensure((size_t)batch * 2 * sizeof(float)));
+  ICA_TRY(launch_minmax(ctx, batch, (size_t)C * H * W, in, ctx->mm_in.as<float>()));
+  // planes go on grid.z (<= 65535): split if needed
+  for (int p0 = 0; p0 < planes; p0 += 32768) {
+    const int np = std::min(32768, planes - p0);
+    hipLaunchKernelGGL(ica_resample_x_kernel, dim3((w + 63) / 64, (H + kWaves - 1) / kWaves, np), dim3(kBlock), 0,
+                       ctx->stream, in + (size_t)p0 * H * W, ctx->tmp_resample.as<float>() + (size_t)p0 * H * w, np, H,
+                       ox->view());
+  }
+  if (C == 1 || (32768 % C) == 0 || planes <= 32768) {
+    const int step = (planes <= 32768) ? planes : (32768 / C) * C;
+    for (int p0 = 0; p0 < planes; p0 += step) {
+      const int np = std::min(step, planes - p0);
+      hipLaunchKernelGGL(ica_resample_y_kernel, dim3((w + 63) / 64, (h + kWaves - 1) / kWaves, np), dim3(kBlock), 0,
+                         ctx->stream, ctx->tmp_resample.as<float>() + (size_t)p0 * H * w, out + (size_t)p0 * h * w, np, C,
+                         w, oy->view(), ctx->mm_in.as<float>() + (size_t)(p0 / C) * 2);
+    }
+  } else {
+    const int step = (32768 / C) * C;
+    for (int p0 = 0; p0 < planes; p0 += step) {
+      const int np = std::min(step, planes - p0);
+      hipLaunchKernelGGL(ica_resample_y_kernel, dim3((w + 63) / 64, (h + kWaves - 1) / kWaves, np), dim3(kBlock), 0,
+                         ctx->stream, ctx->tmp_resample.as<float>() + (size_t)p0 * H * w, out + (size_t)p0 * h * w, np, C,
+                         w, oy->view(), ctx->mm_in.as<float>() + (size_t)(p0 / C) * 2);
+    }
+  }
+  ICA_HIP(ctx, hipGetLastError());
+  return ICA_OK;
+}
+
+template <int TT, int MODE>
+void launch_accumulate_c(int C, dim3 grid, hipStream_t st, const LevelArgs& a) {
+  if (C == 1)
+    hipLaunchKernelGGL((ica_accumulate_kernel<TT, MODE, 1>), grid, dim3(kBlock), 0, st, a);
+  else
+    hipLaunchKernelGGL((ica_accumulate_kernel<TT, MODE, 3>), grid, dim3(kBlock), 0, st, a);
+}
+
+template <int MODE>
+void launch_accumulate(int tt, int C, dim3 grid, hipStream_t st, const LevelArgs& a) {
+  switch (tt) {
+    case ICA_TRANSLATION: launch_accumulate_c<ICA_TRANSLATION, MODE>(C, grid, st, a); break;
+    case ICA_EUCLIDEAN: launch_accumulate_c<ICA_EUCLIDEAN, MODE>(C, grid, st, a); break;
+    case ICA_SIMILARITY: launch_accumulate_c<ICA_SIMILARITY, MODE>(C, grid, st, a); break;
+    case ICA_AFFINITY: launch_accumulate_c<ICA_AFFINITY, MODE>(C, grid, st, a); break;
+    default: launch_accumulate_c<ICA_HOMOGRAPHY, MODE>(C, grid, st, a); break;
+  }
+}
+
+void launch_accumulate_mode(int mode, int tt, int C, dim3 grid, hipStream_t st, const LevelArgs& a) {
+  if (mode == kModeL2) launch_accumulate<kModeL2>(tt, C, grid, st, a);
+  else if (mode == kModeRobust) launch_accumulate<kModeRobust>(tt, C, grid, st, a);
+  else launch_accumulate<kModeHessian>(tt, C, grid, st, a);
+}
+
+int launch_warp(ica_ctx* ctx, int batch, int C, int H, int W, int tt, const float* I2, const double* p,
+                const float* minmax, const float* I1, float* Iw, float* DI) {
+  for (int b0 = 0; b0 < batch; b0 += 32768) {
+    const int nb = std::min(32768, batch - b0);
+    const size_t off = (size_t)b0 * C * H * W;
+    dim3 grid((W + 63) / 64, (H + kWaves - 1) / kWaves, nb);
+    if (C == 1)
+      hipLaunchKernelGGL(ica_warp_kernel<1>, grid, dim3(kBlock), 0, ctx->stream, I2 + off, I1 ? I1 + off : nullptr, H, W,
+                         tt, p + (size_t)b0 * 8, minmax + (size_t)b0 * 2, Iw ? Iw + off : nullptr,
+                         DI ? DI + off : nullptr);
+    else
+      hipLaunchKernelGGL(ica_warp_kernel<3>, grid, dim3(kBlock), 0, ctx->stream, I2 + off, I1 ? I1 + off : nullptr, H, W,
+                         tt, p + (size_t)b0 * 8, minmax + (size_t)b0 * 2, Iw ? Iw + off : nullptr,
+                         DI ? DI + off : nullptr);
+  }
+  ICA_HIP(ctx, hipGetLastError());
+  return ICA_OK;
+}
+
+int ensure_state(ica_ctx* ctx, const ica_problem* pr, const LevelGeom* g) {
+  const size_t B = (size_t)pr->batch;
+  int max_tiles = 1;
+  for (int s = 0; s < pr->nscales; ++s) max_tiles = std::max(max_tiles, g[s].tiles);
+  ICA_HIP(ctx, ctx->partials.ensure(B * max_tiles * kAccStride * sizeof(double)));
+  ICA_HIP(ctx, ctx->hinv.ensure(B * 64 * sizeof(double)));
+  ICA_HIP(ctx, ctx->p_prev.ensure(B * 8 * sizeof(double)));
+  ICA_HIP(ctx, ctx->lambda_it.ensure(B * sizeof(double)));
+  ICA_HIP(ctx, ctx->error.ensure(B * sizeof(double)));
+  ICA_HIP(ctx, ctx->niter.ensure(B * sizeof(int)));
+  ICA_HIP(ctx, ctx->lists.ensure(3 * B * sizeof(int)));
+  ICA_HIP(ctx, ctx->counts.ensure(4 * sizeof(int)));
+  ICA_HIP(ctx, ctx->count_hist.ensure((size_t)pr->nscales * std::max(1, pr->max_iter) * sizeof(int)));
+  ICA_HIP(ctx, ctx->minmax.ensure(B * 2 * sizeof(float)));
+  for (int s = 1; s < pr->nscales; ++s) {
+    const size_t bytes = B * pr->channels * g[s].H * g[s].W * sizeof(float);
+    ICA_HIP(ctx, ctx->pyr1[s].ensure(bytes));
+    ICA_HIP(ctx, ctx->pyr2[s].ensure(bytes));
+    DeviceBandOp* tmp;
+    ICA_TRY(get_op(ctx, g[s - 1].W, g[s].W, &tmp));
+    ICA_TRY(get_op(ctx, g[s - 1].H, g[s].H, &tmp));
+  }
+  if (pr->nscales > 1)
+    ICA_HIP(ctx, ctx->tmp_resample.ensure(B * pr->channels * g[0].H * g[1].W * sizeof(float)));
+  if (!ctx->pinned_count) ICA_HIP(ctx, hipHostMalloc((void**)&ctx->pinned_count, 4 * sizeof(int), hipHostMallocDefault));
+  return ICA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ica_version(void) { return ICA_ABI_VERSION; }
+
+int ica_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* ica_strerror(int status) {
+  switch (status) {
+    case ICA_OK: return "ok";
+    case ICA_EINVAL_SHAPE: return "I1 and I2 must be RGB images with channels in the last dimension";
+    case ICA_EINVAL_DIMS: return "I1 and I2 must have the same dimensions";
+    case ICA_EINVAL_TOL: return "TOL must be positive and very small (less than 0.01)";
+    case ICA_EINVAL_TRANSFORM: return "Unknown transform type";
+    case ICA_EINVAL_ROBUST: return "Unknown type for robust error function";
+    case ICA_EINVAL_ARG: return "invalid argument";
+    case ICA_ENOMEM: return "device memory allocation failed";
+    case ICA_EHIP: return "HIP runtime error";
+    case ICA_ENODEVICE: return "no usable HIP device";
+    default: return "unknown status";
+  }
+}
+
+const char* ica_last_error(const ica_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int ica_create(int device, ica_ctx** out) {
+  if (!out) return ICA_EINVAL_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return ICA_ENODEVICE;
+  if (hipSetDevice(device) != hipSuccess) return ICA_ENODEVICE;
+  auto* c = new ica_ctx();
+  c->device = device;
+  if (const char* e = getenv("ICA_POLL_EVERY")) c->poll_every = std::max(1, atoi(e));
+  *out = c;
+  return ICA_OK;
+}
+
+int ica_destroy(ica_ctx* ctx) {
+  if (!ctx) return ICA_EINVAL_ARG;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  delete ctx;
+  return ICA_OK;
+}
+
+int ica_set_stream(ica_ctx* ctx, void* s) {
+  if (!ctx) return ICA_EINVAL_ARG;
+  ctx->stream = reinterpret_cast<hipStream_t>(s);
+  return ICA_OK;
+}
+
+int ica_synchronize(ica_ctx* ctx) {
+  if (!ctx) return ICA_EINVAL_ARG;
+  ICA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ICA_OK;
+}
+
+int ica_set_profiling(ica_ctx* ctx, int on) {
+  if (!ctx) return ICA_EINVAL_ARG;
+  ctx->profiling = on != 0;
+  return ICA_OK;
+}
+
+int ica_nparams(int tt) { return nparams_of(tt); }
+
+int ica_zoom_size(int width, int height, double nu, int* ow, int* oh) {
+  if (!ow || !oh) return ICA_EINVAL_ARG;
+  *ow = round_half_even(width * nu);
+  *oh = round_half_even(height * nu);
+  return ICA_OK;
+}
+
+int ica_prepare(ica_ctx* ctx, const ica_problem* pr) {
+  if (!ctx) return ICA_EINVAL_ARG;
+  ICA_TRY(validate(pr));
+  ICA_HIP(ctx, hipSetDevice(ctx->device));
+  LevelGeom g[ICA_MAX_SCALES];
+  level_sizes(pr, g);
+  return ensure_state(ctx, pr, g);
+}
+
+int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, const float* I2, double* p,
+                        double* error_out, int32_t* niter_out, float* DI_out, float* Iw_out, double* trace_out,
+                        ica_stats* stats) {
+  if (!ctx || !I1 || !I2 || !p || !error_out || !niter_out) return ICA_EINVAL_ARG;
+  ICA_TRY(validate(pr));
+  ICA_HIP(ctx, hipSetDevice(ctx->device));
+  LevelGeom g[ICA_MAX_SCALES];
+  level_sizes(pr, g);
+  ICA_TRY(ensure_state(ctx, pr, g));
+  hipStream_t st = ctx->stream;
+  const int B = pr->batch, C = pr->channels, tt = pr->transform_type, n = nparams_of(tt);
+  const bool robust = pr->robust_type != ICA_QUADRATIC;
+  const int ns = pr->nscales, max_iter = pr->max_iter;
+
+  // ---- pyramid (ref :331-337) ----
+  const float* L1[ICA_MAX_SCALES];
+  const float* L2[ICA_MAX_SCALES];
+  L1[0] = I1;
+  L2[0] = I2;
+  for (int s = 1; s < ns; ++s) {
+    ICA_TRY(launch_pyramid_down(ctx, B, C, g[s - 1].H, g[s - 1].W, g[s].H, g[s].W, L1[s - 1], ctx->pyr1[s].as<float>()));
+    ICA_TRY(launch_pyramid_down(ctx, B, C, g[s - 1].H, g[s - 1].W, g[s].H, g[s].W, L2[s - 1], ctx->pyr2[s].as<float>()));
+    L1[s] = ctx->pyr1[s].as<float>();
+    L2[s] = ctx->pyr2[s].as<float>();
+  }
+  ICA_HIP(ctx, hipMemsetAsync(ctx->count_hist.ptr, 0, (size_t)ns * std::max(1, max_iter) * sizeof(int), st));
+  if (trace_out)
+    ICA_HIP(ctx, hipMemsetAsync(trace_out, 0, (size_t)B * ns * max_iter * ICA_TRACE_STRIDE * sizeof(double), st));
+  ICA_HIP(ctx, hipMemsetAsync(niter_out, 0, (size_t)B * ns * sizeof(int32_t), st));
+
+  int* lists = ctx->lists.as<int>();
+  int* counts = ctx->counts.as<int>();
+  struct EvRec { int level; size_t e0, e1; };
+  std::vector<EvRec> evrecs;
+  size_t ev_used = 0;
+  auto next_event = [&](size_t* idx) -> int {
+    if (ev_used == ctx->ev_pool.size()) {
+      hipEvent_t e;
+      ICA_HIP(ctx, hipEventCreate(&e));
+      ctx->ev_pool.push_back(e);
+    }
+    *idx = ev_used++;
+    return ICA_OK;
+  };
+  int64_t launches[ICA_MAX_SCALES] = {0};
+
+  // ---- coarse to fine (ref :340-372) ----
+  for (int s = ns - 1; s >= 0; --s) {
+    ICA_TRY(launch_minmax(ctx, B, (size_t)C * g[s].H * g[s].W, L2[s], ctx->minmax.as<float>()));
+    LevelInitArgs li{};
+    li.batch = B; li.tt = tt; li.level = s; li.nscales = ns;
+    if (s < ns - 1) { li.w_coarse = g[s + 1].W; li.h_coarse = g[s + 1].H; li.w_fine = g[s].W; li.h_fine = g[s].H; }
+    li.lambda_user = pr->lambda; li.lambda0 = pr->lambda0;
+    li.p = p; li.lambda_it = ctx->lambda_it.as<double>(); li.error = ctx->error.as<double>();
+    li.niter = ctx->niter.as<int>(); li.niter_out = niter_out; li.list0 = lists; li.counts = counts;
+    hipLaunchKernelGGL(ica_level_init_kernel, dim3((B + 255) / 256), dim3(256), 0, st, li);
+
+    LevelArgs la{};
+    la.I1 = L1[s]; la.I2 = L2[s]; la.H = g[s].H; la.W = g[s].W;
+    la.tiles_x = g[s].tiles_x; la.tiles_y = g[s].tiles_y; la.tile_h = g[s].tile_h;
+    la.delta = pr->delta; la.nanif = pr->nanifoutside; la.robust_type = pr->robust_type;
+    la.p = p; la.lambda_it = ctx->lambda_it.as<double>(); la.minmax = ctx->minmax.as<float>();
+    la.partials = ctx->partials.as<double>();
+
+    if (!robust) {  // ref :96-103: steepest-descent Hessian and its inverse, once per level
+      la.act_list = nullptr; la.act_count = nullptr;
+      launch_accumulate_mode(kModeHessian, tt, C, dim3(g[s].tiles, B), st, la);
+      hipLaunchKernelGGL(ica_setup_solve_kernel, dim3(B), dim3(64), 0, st, la.partials, g[s].tiles, n,
+                         ctx->hinv.as<double>());
+    }
+
+    int nb = B;  // upper bound of the number of active pairs
+    for (int it = 0; it < max_iter && nb > 0; ++it) {
+      const int cur = it % 3, nxt = (it + 1) % 3, clr = (it + 2) % 3;
+      la.act_list = lists + (size_t)cur * B;
+      la.act_count = counts + cur;
+      size_t e0 = 0, e1 = 0;
+      if (ctx->profiling) {
+        ICA_TRY(next_event(&e0));
+        ICA_HIP(ctx, hipEventRecord(ctx->ev_pool[e0], st));
+      }
+      launch_accumulate_mode(robust ? kModeRobust : kModeL2, tt, C, dim3(g[s].tiles, nb), st, la);
+      if (ctx->profiling) {
+        ICA_TRY(next_event(&e1));
+        ICA_HIP(ctx, hipEventRecord(ctx->ev_pool[e1], st));
+        evrecs.push_back({s, e0, e1});
+      }
+      launches[s]++;
+      SolveArgs sa{};
+      sa.tt = tt; sa.n = n; sa.robust = robust; sa.flags = pr->flags; sa.tiles = g[s].tiles; sa.max_iter = max_iter;
+      sa.level = s; sa.nscales = ns; sa.iter = it; sa.tol = pr->tol; sa.lambda_user = pr->lambda;
+      sa.lambdaN = pr->lambdaN; sa.lambda_ratio = pr->lambda_ratio;
+      sa.partials = la.partials; sa.p = p; sa.p_prev = ctx->p_prev.as<double>(); sa.Hinv = ctx->hinv.as<double>();
+      sa.lambda_it = ctx->lambda_it.as<double>(); sa.error = ctx->error.as<double>(); sa.niter = ctx->niter.as<int>();
+      sa.cur_list = lists + (size_t)cur * B; sa.cur_count = counts + cur;
+      sa.nxt_list = lists + (size_t)nxt * B; sa.nxt_count = counts + nxt; sa.clr_count = counts + clr;
+      sa.count_hist = ctx->count_hist.as<int>(); sa.trace = trace_out;
+      hipLaunchKernelGGL(ica_solve_kernel, dim3(nb), dim3(64), 0, st, sa);
+      if ((it + 1) % ctx->poll_every == 0 && it + 1 < max_iter) {
+        // shrink the grid to the pairs that are still iterating (the count only ever decreases)
+        ICA_HIP(ctx, hipMemcpyAsync(ctx->pinned_count, counts + nxt, sizeof(int), hipMemcpyDeviceToHost, st));
+        ICA_HIP(ctx, hipStreamSynchronize(st));
+        nb = ctx->pinned_count[0];
+      }
+    }
+    ICA_HIP(ctx, hipGetLastError());
+  }
+  hipLaunchKernelGGL(ica_finish_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, ns, ctx->niter.as<int>(),
+                     ctx->error.as<double>(), niter_out, error_out);
+  if (DI_out || Iw_out) {
+    // Iw / DI of the last executed iteration at scale 0 = warp under the parameters BEFORE the last
+    // update (ref :111-114 then :123, returned at :133).  minmax still holds the scale-0 range.
+    ICA_TRY(launch_warp(ctx, B, C, g[0].H, g[0].W, tt, I2, ctx->p_prev.as<double>(), ctx->minmax.as<float>(), I1,
+                        Iw_out, DI_out));
+  }
+  ICA_HIP(ctx, hipGetLastError());
+
+  if (stats) {
+    memset(stats, 0, sizeof(*stats));
+    std::vector<int> hist((size_t)ns * std::max(1, max_iter));
+    ICA_HIP(ctx, hipMemcpyAsync(hist.data(), ctx->count_hist.ptr, hist.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+    ICA_HIP(ctx, hipStreamSynchronize(st));
+    for (int s = 0; s < ns; ++s) {
+      int64_t units = 0;
+      for (int it = 0; it < max_iter; ++it) units += hist[(size_t)s * max_iter + it];
+      stats->pair_iterations[s] = units;
+      stats->pair_iterations_total += units;
+      stats->iter_launches[s] = launches[s];
+      stats->iter_kernel_bytes[s] = (double)units * 2.0 * g[s].H * g[s].W * C * 4.0;
+      stats->level_width[s] = g[s].W;
+      stats->level_height[s] = g[s].H;
+    }
+    for (const auto& r : evrecs) {
+      float ms = 0.f;
+      ICA_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[r.e0], ctx->ev_pool[r.e1]));
+      stats->iter_kernel_ms[r.level] += ms;
+    }
+  }
+  return ICA_OK;
+}
+
+int ica_solve_batch(ica_ctx* ctx, const ica_problem* pr, const float* I1, const float* I2, double* p, double* error_out,
+                    int32_t* niter_out, float* DI_out, float* Iw_out, double* trace_out, ica_stats* stats) {
+  if (!ctx || !I1 || !I2 || !p || !error_out || !niter_out) return ICA_EINVAL_ARG;
+  ICA_TRY(validate(pr));
+  ICA_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t B = pr->batch, img = B * pr->channels * pr->height * pr->width;
+  const size_t tr = B * pr->nscales * pr->max_iter * ICA_TRACE_STRIDE;
+  DevBuf d1, d2, dp, de, dn, dDI, dIw, dtr;
+  auto cleanup = [&]() { d1.release(); d2.release(); dp.release(); de.release(); dn.release(); dDI.release(); dIw.release(); dtr.release(); };
+  int rc = ICA_OK;
+  auto H = [&](hipError_t e, const char* what) {
+    if (e != hipSuccess && rc == ICA_OK) {
+      ctx->last_error = std::string(what) + ": " + hipGetErrorString(e);
+      rc = e == hipErrorOutOfMemory ? ICA_ENOMEM : ICA_EHIP;
+    }
+  };
+  H(d1.ensure(img * 4), "alloc I1"); H(d2.ensure(img * 4), "alloc I2"); H(dp.ensure(B * 8 * 8), "alloc p");
+  H(de.ensure(B * 8), "alloc err"); H(dn.ensure(B * pr->nscales * 4), "alloc niter");
+  if (DI_out) H(dDI.ensure(img * 4), "alloc DI");
+  if (Iw_out) H(dIw.ensure(img * 4), "alloc Iw");
+  if (trace_out) H(dtr.ensure(std::max<size_t>(tr, 1) * 8), "alloc trace");
+  if (rc == ICA_OK) {
+    H(hipMemcpyAsync(d1.ptr, I1, img * 4, hipMemcpyHostToDevice, ctx->stream), "copy I1");
+    H(hipMemcpyAsync(d2.ptr, I2, img * 4, hipMemcpyHostToDevice, ctx->stream), "copy I2");
+    H(hipMemcpyAsync(dp.ptr, p, B * 64, hipMemcpyHostToDevice, ctx->stream), "copy p");
+  }
+  if (rc == ICA_OK)
+    rc = ica_solve_batch_dev(ctx, pr, d1.as<float>(), d2.as<float>(), dp.as<double>(), de.as<double>(), dn.as<int32_t>(),
+                             DI_out ? dDI.as<float>() : nullptr, Iw_out ? dIw.as<float>() : nullptr,
+                             trace_out ? dtr.as<double>() : nullptr, stats);
+  if (rc == ICA_OK) {
+    H(hipMemcpyAsync(p, dp.ptr, B * 64, hipMemcpyDeviceToHost, ctx->stream), "copy p back");
+    H(hipMemcpyAsync(error_out, de.ptr, B * 8, hipMemcpyDeviceToHost, ctx->stream), "copy err back");
+    H(hipMemcpyAsync(niter_out, dn.ptr, B * pr->nscales * 4, hipMemcpyDeviceToHost, ctx->stream), "copy niter back");
+    if (DI_out) H(hipMemcpyAsync(DI_out, dDI.ptr, img * 4, hipMemcpyDeviceToHost, ctx->stream), "copy DI back");
+    if (Iw_out) H(hipMemcpyAsync(Iw_out, dIw.ptr, img * 4, hipMemcpyDeviceToHost, ctx->stream), "copy Iw back");
+    if (trace_out && tr) H(hipMemcpyAsync(trace_out, dtr.ptr, tr * 8, hipMemcpyDeviceToHost, ctx->stream), "copy trace back");
+    H(hipStreamSynchronize(ctx->stream), "sync");
+  } else {
+    (void)hipStreamSynchronize(ctx->stream);
+  }
+  cleanup();
+  return rc;
+}
+
+// ---- per-operator hooks --------------------------------------------------------------------------
+
+int ica_op_minmax_dev(ica_ctx* ctx, int batch, int channels, int height, int width, const float* I, float* out) {
+  if (!ctx || !I || !out || batch <= 0 || channels <= 0 || height <= 0 || width <= 0) return ICA_EINVAL_ARG;
+  ICA_HIP(ctx, hipSetDevice(ctx->device));
+  return launch_minmax(ctx, batch, (size_t)channels * height * width, I, out);
+}
+
+int ica_op_warp_dev(ica_ctx* ctx, int batch, int channels, int height, int width, int tt, const float* I2,
+                    const double* p, const float* minmax, const float* I1, float* Iw_out, float* DI_out) {
+  if (!ctx || !I2 || !p || batch <= 0 || height <= 0 || width <= 0) return ICA_EINVAL_ARG;
+  if (channels != 1 && channels != 3) return ICA_EINVAL_SHAPE;
+  if (nparams_of(tt) < 0) return ICA_EINVAL_TRANSFORM;
+  if (DI_out && !I1) return ICA_EINVAL_ARG;
+  ICA_HIP(ctx, hipSetDevice(ctx->device));
+  if (!minmax) {
+    ICA_HIP(ctx, ctx->minmax.ensure((size_t)batch * 2 * sizeof(float)));
+    ICA_TRY(launch_minmax(ctx, batch, (size_t)channels * height * width, I2, ctx->minmax.as<float>()));
+    minmax = ctx->minmax.as<float>();
+  }
+  return launch_warp(ctx, batch, channels, height, width, tt, I2, p, minmax, I1, Iw_out, DI_out);
+}
+
+int ica_op_normal_equations_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, const float* I2, const double* p,
+                                const double* lambda_it, double* H_out, double* b_out) {
+  if (!ctx || !I1 || !I2 || !p || !H_out || !b_out) return ICA_EINVAL_ARG;
+  ICA_TRY(validate(pr));
+  const bool robust = pr->robust_type != ICA_QUADRATIC;
+  if (robust && !lambda_it) return ICA_EINVAL_ARG;
+  ICA_HIP(ctx, hipSetDevice(ctx->device));
+  ica_problem one = *pr;
+  one.nscales = 1;
+  LevelGeom g[ICA_MAX_SCALES];
+  level_sizes(&one, g);
+  ICA_TRY(ensure_state(ctx, &one, g));
+  const int B = pr->batch, C = pr->channels, tt = pr->transform_type, n = nparams_of(tt);
+  ICA_TRY(launch_minmax(ctx, B, (size_t)C * g[0].H * g[0].W, I2, ctx->minmax.as<float>()));
+  LevelArgs la{};
+  la.I1 = I1; la.I2 = I2; la.H = g[0].H; la.W = g[0].W;
+  la.tiles_x = g[0].tiles_x; la.tiles_y = g[0].tiles_y; la.tile_h = g[0].tile_h;
+  la.delta = pr->delta; la.nanif = pr->nanifoutside; la.robust_type = pr->robust_type;
+  la.p = p; la.lambda_it = lambda_it; la.minmax = ctx->minmax.as<float>();
+  la.partials = ctx->partials.as<double>();
+  la.act_list = nullptr; la.act_count = nullptr;
+  if (robust) {
+    launch_accumulate_mode(kModeRobust, tt, C, dim3(g[0].tiles, B), ctx->stream, la);
+    hipLaunchKernelGGL(ica_gather_normal_equations_kernel, dim3(B), dim3(64), 0, ctx->stream, la.partials, g[0].tiles, n,
+                       B, 1, 1, (const double*)nullptr, H_out, b_out);
+  } else {
+    launch_accumulate_mode(kModeHessian, tt, C, dim3(g[0].tiles, B), ctx->stream, la);
+    hipLaunchKernelGGL(ica_gather_normal_equations_kernel, dim3(B), dim3(64), 0, ctx->stream, la.partials, g[0].tiles, n,
+                       B, 0, 1, (const double*)nullptr, H_out, b_out);
+    launch_accumulate_mode(kModeL2, tt, C, dim3(g[0].tiles, B), ctx->stream, la);
+    hipLaunchKernelGGL(ica_gather_normal_equations_kernel, dim3(B), dim3(64), 0, ctx->stream, la.partials, g[0].tiles, n,
+                       B, 1, 0, (const double*)nullptr, H_out, b_out);
+  }
+  ICA_HIP(ctx, hipGetLastError());
+  return ICA_OK;
+}
+
+int ica_op_solve_update_dev(ica_ctx* ctx, int batch, int tt, int flags, const double* H, const double* b, double* p,
+                            double* dp_out, double* error_out) {
+  if (!ctx || !H || !b || !p || batch <= 0) return ICA_EINVAL_ARG;
+  if (nparams_of(tt) < 0) return ICA_EINVAL_TRANSFORM;
+  ICA_HIP(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(ica_solve_update_kernel, dim3((batch + 63) / 64), dim3(64), 0, ctx->stream, batch, tt, flags, H, b, p,
+                     dp_out, error_out);
+  ICA_HIP(ctx, hipGetLastError());
+  return ICA_OK;
+}
+
+int ica_op_pyramid_down_dev(ica_ctx* ctx, int batch, int channels, int height, int width, double nu, const float* in,
+                            float* out) {
+  if (!ctx || !in || !out || batch <= 0 || channels <= 0 || height <= 0 || width <= 0 || !(nu > 0)) return ICA_EINVAL_ARG;
+  ICA_HIP(ctx, hipSetDevice(ctx->device));
+  const int w = std::max(1, round_half_even(width * nu)), h = std::max(1, round_half_even(height * nu));
+  return launch_pyramid_down(ctx, batch, channels, height, width, h, w, in, out);
+}
+
+int ica_op_zoom_in_parameters_dev(ica_ctx* ctx, int batch, int tt, int w, int h, int ww, int hh, double* p) {
+  if (!ctx || !p || batch <= 0 || w <= 0 || h <= 0) return ICA_EINVAL_ARG;
+  if (nparams_of(tt) < 0) return ICA_EINVAL_TRANSFORM;
+  ICA_HIP(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(ica_zoom_params_kernel, dim3((batch + 255) / 256), dim3(256), 0, ctx->stream, batch, tt, w, h, ww, hh, p);
+  ICA_HIP(ctx, hipGetLastError());
+  return ICA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,581 @@
+// HIP kernels of the inverse-compositional hot path for gfx950 (wave64).
+//
+// Data layout (HBM): images float32 planar [B][C][H][W]; per-pair state float64.
+// The reference materialises gradient, Jacobian and steepest-descent tensors (192 B/pixel for
+// C=3, n=8).  Here nothing but the two images is ever read per iteration: gradients, Jacobian rows,
+// steepest-descent values and robust weights are recomputed in registers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "ica_math.hpp"
+
+namespace ica {
+
+constexpr int kBlock = 256;   // 4 waves
+constexpr int kTileW = 64;    // one lane per column of a tile
+constexpr int kWaves = kBlock / 64;
+constexpr int kFlush = 8;     // fp32 partial sums are promoted to fp64 every kFlush pixels per thread
+
+enum Mode { kModeL2 = 0, kModeRobust = 1, kModeHessian = 2 };
+
+struct LevelArgs {
+  const float* I1;
+  const float* I2;
+  int H, W;
+  int tiles_x, tiles_y, tile_h;
+  int delta, nanif;
+  int robust_type;
+  const double* p;          // [B][8]
+  const double* lambda_it;  // [B]
+  const float* minmax;      // [B][2] clip range of I2 at this level
+  const int* act_list;      // current active pairs (nullptr: pair = blockIdx.y)
+  const int* act_count;
+  double* partials;         // [B][tiles][kAccStride]
+};
+
+template <int TT> struct NP;
+template <> struct NP<ICA_TRANSLATION> { static constexpr int n = 2; };
+template <> struct NP<ICA_EUCLIDEAN> { static constexpr int n = 3; };
+template <> struct NP<ICA_SIMILARITY> { static constexpr int n = 4; };
+template <> struct NP<ICA_AFFINITY> { static constexpr int n = 6; };
+template <> struct NP<ICA_HOMOGRAPHY> { static constexpr int n = 8; };
+
+// Steepest-descent row  D[k] = Ix*Jx[k] + Iy*Jy[k]  (image_optimisation.py:190-192) with the Jacobian
+// rows of derivatives.py:33-68; x = column, y = row, integer pixel indices.
+template <int TT>
+__device__ __forceinline__ void steepest_descent(float ix, float iy, float x, float y, float* D) {
+  if constexpr (TT == ICA_TRANSLATION) {
+    D[0] = ix; D[1] = iy;
+  } else if constexpr (TT == ICA_EUCLIDEAN) {
+    D[0] = ix; D[1] = iy; D[2] = x * iy - y * ix;
+  } else if constexpr (TT == ICA_SIMILARITY) {
+    D[0] = ix; D[1] = iy; D[2] = x * ix + y * iy; D[3] = x * iy - y * ix;
+  } else if constexpr (TT == ICA_AFFINITY) {
+    D[0] = ix; D[1] = iy; D[2] = x * ix; D[3] = y * ix; D[4] = x * iy; D[5] = y * iy;
+  } else {
+    const float s = x * ix + y * iy;
+    D[0] = x * ix; D[1] = y * ix; D[2] = ix; D[3] = x * iy; D[4] = y * iy; D[5] = iy;
+    D[6] = -x * s; D[7] = -y * s;
+  }
+}
+
+// Displacement (dx, dy) = W(x;p) - x in fp32.  Working on the displacement instead of the absolute
+// position keeps every term small (|d| is tens of pixels at most), so fp32 resolves the sampling
+// position to ~1e-6 px even at x ~ 2000.
+template <bool PROJ>
+__device__ __forceinline__ void displacement(const float* a, float x, float y, float& dx, float& dy) {
+  float nx = fmaf(a[0], x, fmaf(a[1], y, a[2]));
+  float ny = fmaf(a[3], x, fmaf(a[4], y, a[5]));
+  if constexpr (PROJ) {
+    const float g = fmaf(a[6], x, a[7] * y);
+    const float r = 1.0f / (1.0f + g);
+    nx = (nx - x * g) * r;
+    ny = (ny - y * g) * r;
+  }
+  dx = nx;
+  dy = ny;
+}
+
+__device__ __forceinline__ void keys_weights(float t, float* w) {
+  // Catmull-Rom (Keys a = -1/2), the cubic of skimage's _warp_fast / bicubic_interpolation.py:39-41
+  w[0] = ((-0.5f * t + 1.0f) * t - 0.5f) * t;
+  w[1] = (1.5f * t - 2.5f) * t * t + 1.0f;
+  w[2] = ((-1.5f * t + 2.0f) * t + 0.5f) * t;
+  w[3] = (0.5f * t - 0.5f) * t * t;
+}
+
+// Bicubic sample of C planes at (x+dx, y+dy); false (and nothing written) when any of the 16 taps is
+// outside the image -- the reference's NaN (bicubic_interpolation.py:199, cval=nan).  The result is
+// clipped to [lo, hi] as skimage.transform.warp(clip=True) does.
+template <int C>
+__device__ __forceinline__ bool warp_sample(const float* __restrict__ img, int H, int W, int x, int y,
+                                            float dx, float dy, float lo, float hi, float* out) {
+  const float flx = floorf(dx), fly = floorf(dy);
+  const int x0 = x + (int)flx, y0 = y + (int)fly;
+  const bool ok = (x0 >= 1) & (x0 <= W - 3) & (y0 >= 1) & (y0 <= H - 3);
+  if (!ok) return false;
+  float wx[4], wy[4];
+  keys_weights(dx - flx, wx);
+  keys_weights(dy - fly, wy);
+  const size_t plane = (size_t)H * W;
+  const float* base = img + (size_t)(y0 - 1) * W + (x0 - 1);
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const float* q = base + c * plane;
+    float v = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float* row = q + (size_t)r * W;
+      const float s = wx[0] * row[0] + wx[1] * row[1] + wx[2] * row[2] + wx[3] * row[3];
+      v = fmaf(wy[r], s, v);
+    }
+    out[c] = fminf(fmaxf(v, lo), hi);
+  }
+  return true;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;  // valid in lane 0
+}
+
+// The fused per-iteration pass (ref :111-117 / :227-244 and the setup Hessian :96-102):
+//   MODE kModeL2      b = sum DIJ^T DI                      over F & V(p)
+//   MODE kModeRobust  b and H = sum rho' DIJ^T DIJ           (rho'(0) where the warp is outside)
+//   MODE kModeHessian H = sum DIJ^T DIJ over F               (L2 setup, no warp)
+// F = pixels outside the NaN frame, V(p) = pixels whose 4x4 footprint is inside I2.
+// One workgroup = one 64 x tile_h tile of one pair; lane = column, the 4 waves interleave rows.
+template <int TT, int MODE, int C>
+__global__ __launch_bounds__(kBlock) void ica_accumulate_kernel(LevelArgs a) {
+  constexpr int N = NP<TT>::n;
+  constexpr int NT = N * (N + 1) / 2;
+  constexpr bool kB = (MODE != kModeHessian);
+  constexpr bool kH = (MODE != kModeL2);
+  constexpr bool kProj = (TT == ICA_HOMOGRAPHY);
+
+  int pair = blockIdx.y;
+  if (a.act_list) {
+    if ((int)blockIdx.y >= *a.act_count) return;
+    pair = a.act_list[blockIdx.y];
+  }
+  const int tile = blockIdx.x;
+  const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int H = a.H, W = a.W;
+  const size_t plane = (size_t)H * W;
+  const float* I1 = a.I1 + (size_t)pair * C * plane;
+  const float* I2 = a.I2 + (size_t)pair * C * plane;
+
+  float A[8];
+  float lo = 0.f, hi = 0.f, lam2 = 0.f;
+  if constexpr (kB) {
+    double ad[8];
+    params_to_displacement(a.p + (size_t)pair * 8, TT, ad);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) A[i] = (float)ad[i];
+    lo = a.minmax[pair * 2];
+    hi = a.minmax[pair * 2 + 1];
+    if constexpr (MODE == kModeRobust) {
+      const float l = (float)a.lambda_it[pair];
+      lam2 = l * l;
+    }
+  }
+
+  float bacc[N], hacc[NT];
+  double bsum[N], hsum[NT];
+#pragma unroll
+  for (int k = 0; k < N; ++k) { bacc[k] = 0.f; bsum[k] = 0.0; }
+#pragma unroll
+  for (int k = 0; k < NT; ++k) { hacc[k] = 0.f; hsum[k] = 0.0; }
+
+  const int x = tx * kTileW + lane;
+  const int y_begin = ty * a.tile_h;
+  const int y_end = min(H, y_begin + a.tile_h);
+  const bool frame_on = a.nanif && a.delta > 0;
+  const bool col_ok = (x < W) && !(frame_on && (x < a.delta || x >= W - a.delta));
+  const float xf = (float)x;
+  int since_flush = 0;
+
+  for (int y = y_begin + wave; y < y_end; y += kWaves) {
+    const bool row_ok = !(frame_on && (y < a.delta || y >= H - a.delta));  // wave-uniform
+    if (row_ok) {
+      const bool act = col_ok;
+      const float yf = (float)y;
+      float di[C], D[C][N];
+      bool valid = false;
+      if (act) {
+        float dxw = 0.f, dyw = 0.f;
+        float iw[C];
+        if constexpr (kB) {
+          displacement<kProj>(A, xf, yf, dxw, dyw);
+          valid = warp_sample<C>(I2, H, W, x, y, dxw, dyw, lo, hi, iw);
+        }
+        const float* c1 = I1 + (size_t)y * W + x;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const float* q = c1 + c * plane;
+          const float ix = (x >= 1 && x <= W - 2) ? 0.5f * (q[1] - q[-1]) : 0.0f;       // ref :81
+          const float iy = (y >= 1 && y <= H - 2) ? 0.5f * (q[W] - q[-(ptrdiff_t)W]) : 0.0f;  // ref :82
+          steepest_descent<TT>(ix, iy, xf, yf, D[c]);
+          if constexpr (kB) {
+            const float d = valid ? iw[c] - q[0] : 0.0f;                               // ref :114
+            di[c] = (fabsf(d) <= 3.0e38f) ? d : 0.0f;                                  // non-finite -> 0
+          }
+        }
+        float w = 1.0f;
+        if constexpr (MODE == kModeRobust) {
+          float t2 = 0.f;
+#pragma unroll
+          for (int c = 0; c < C; ++c) t2 = fmaf(di[c], di[c], t2);                     // io.py:74-76
+          w = rho_prime(t2, lam2, a.robust_type);
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          if constexpr (kB) {
+            const float wd = w * di[c];
+#pragma unroll
+            for (int k = 0; k < N; ++k) bacc[k] = fmaf(wd, D[c][k], bacc[k]);
+          }
+          if constexpr (kH) {
+            int idx = 0;
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+              const float wk = w * D[c][k];
+#pragma unroll
+              for (int m = k; m < N; ++m) { hacc[idx] = fmaf(wk, D[c][m], hacc[idx]); ++idx; }
+            }
+          }
+        }
+      }
+      if (++since_flush == kFlush) {
+        since_flush = 0;
+        if constexpr (kB) {
+#pragma unroll
+          for (int k = 0; k < N; ++k) { bsum[k] += (double)bacc[k]; bacc[k] = 0.f; }
+        }
+        if constexpr (kH) {
+#pragma unroll
+          for (int k = 0; k < NT; ++k) { hsum[k] += (double)hacc[k]; hacc[k] = 0.f; }
+        }
+      }
+    }
+  }
+  if constexpr (kB) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) bsum[k] += (double)bacc[k];
+  }
+  if constexpr (kH) {
+#pragma unroll
+    for (int k = 0; k < NT; ++k) hsum[k] += (double)hacc[k];
+  }
+
+  // fixed-order reduction: lanes (shuffle tree) -> 4 waves (LDS, summed in wave order) -> one partial
+  __shared__ double red[kWaves][kAccStride];
+  if constexpr (kB) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const double s = wave_sum(bsum[k]);
+      if (lane == 0) red[wave][k] = s;
+    }
+  }
+  if constexpr (kH) {
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+      const double s = wave_sum(hsum[k]);
+      if (lane == 0) red[wave][kMaxN + k] = s;
+    }
+  }
+  __syncthreads();
+  double* out = a.partials + ((size_t)pair * (a.tiles_x * a.tiles_y) + tile) * kAccStride;
+  const int t = threadIdx.x;
+  if (kB && t < N) out[t] = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
+  if (kH && t >= kMaxN && t < kMaxN + NT) out[t] = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
+}
+
+// ---- per-pair small kernels ---------------------------------------------------------------------
+
+struct SolveArgs {
+  int tt, n, robust, flags;
+  int tiles;
+  int max_iter;
+  int level, nscales;
+  int iter;               // iteration index of this launch (for the count history)
+  double tol, lambda_user, lambdaN, lambda_ratio;
+  const double* partials;
+  double* p;              // [B][8]
+  double* p_prev;         // [B][8]
+  double* Hinv;           // [B][64] (L2: read, robust: scratch not used)
+  double* lambda_it;      // [B]
+  double* error;          // [B]
+  int* niter;             // [B]
+  const int* cur_list; const int* cur_count;
+  int* nxt_list; int* nxt_count;
+  int* clr_count;
+  int* count_hist;        // [nscales][max_iter]
+  double* trace;          // nullable [B][nscales][max_iter][10]
+};
+
+// Sum the tile partials of one pair in tile order (deterministic), lanes 0..43 one accumulator each.
+__device__ __forceinline__ void gather_partials(const double* partials, int pair, int tiles, double* s /*LDS[44]*/) {
+  const int k = threadIdx.x;
+  if (k < kAccStride) {
+    const double* q = partials + (size_t)pair * tiles * kAccStride + k;
+    double acc = 0.0;
+    for (int t = 0; t < tiles; ++t) acc += q[(size_t)t * kAccStride];
+    s[k] = acc;
+  }
+  __syncthreads();
+}
+
+// L2 setup: H^-1 once per level (ref :102-103).
+__global__ __launch_bounds__(64) void ica_setup_solve_kernel(const double* partials, int tiles, int n, double* Hinv) {
+  __shared__ double s[kAccStride];
+  const int pair = blockIdx.x;
+  gather_partials(partials, pair, tiles, s);
+  if (threadIdx.x == 0) {
+    double Hm[kMaxN * kMaxN];
+    for (int k = 0; k < n; ++k)
+      for (int m = k; m < n; ++m) Hm[k * kMaxN + m] = Hm[m * kMaxN + k] = s[kMaxN + tri_index(k, m, n)];
+    lu_inverse(n, Hm, Hinv + (size_t)pair * 64, kMaxN);
+  }
+}
+
+// Solve + compositional update + loop control for one active pair (ref :117-131 / :233-259).
+__global__ __launch_bounds__(64) void ica_solve_kernel(SolveArgs a) {
+  __shared__ double s[kAccStride];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    *a.clr_count = 0;
+    if (a.count_hist) a.count_hist[a.level * a.max_iter + a.iter] = *a.cur_count;
+  }
+  if ((int)blockIdx.x >= *a.cur_count) return;
+  const int pair = a.cur_list[blockIdx.x];
+  gather_partials(a.partials, pair, a.tiles, s);
+  if (threadIdx.x != 0) return;
+  const int n = a.n;
+  double Hm[kMaxN * kMaxN], Hi[kMaxN * kMaxN];
+  const double* hinv = a.Hinv + (size_t)pair * 64;
+  if (a.robust) {
+    for (int k = 0; k < n; ++k)
+      for (int m = k; m < n; ++m) Hm[k * kMaxN + m] = Hm[m * kMaxN + k] = s[kMaxN + tri_index(k, m, n)];
+    lu_inverse(n, Hm, Hi, kMaxN);  // derivatives.py:110-130 (zeros if singular)
+    hinv = Hi;
+  }
+  double dp[kMaxN], e2 = 0.0;
+  for (int i = 0; i < n; ++i) {  // image_optimisation.py:146-155
+    double v = 0.0;
+    for (int j = 0; j < n; ++j) v += hinv[i * kMaxN + j] * s[j];
+    dp[i] = v;
+    e2 += v * v;
+  }
+  const double err = sqrt(e2);
+  double* p = a.p + (size_t)pair * 8;
+  double* pp = a.p_prev + (size_t)pair * 8;
+  for (int i = 0; i < 8; ++i) pp[i] = p[i];
+  update_transform(p, dp, a.tt, (a.flags & ICA_FLAG_EXACT_UPDATE) != 0);  // transformation.py:35-141
+  double lam = a.lambda_it[pair];
+  if (a.robust && a.lambda_user <= 0.0 && lam > a.lambdaN) {  // ref :235-238 (decay after use)
+    lam *= a.lambda_ratio;
+    if (lam < a.lambdaN) lam = a.lambdaN;
+    a.lambda_it[pair] = lam;
+  }
+  const int it = a.niter[pair];
+  if (a.trace) {
+    double* tr = a.trace + (((size_t)pair * a.nscales + a.level) * a.max_iter + it) * ICA_TRACE_STRIDE;
+    tr[0] = err;
+    for (int i = 0; i < 8; ++i) tr[1 + i] = (i < n) ? p[i] : 0.0;
+    tr[9] = lam;
+  }
+  a.error[pair] = err;
+  a.niter[pair] = it + 1;
+  if (err > a.tol && it + 1 < a.max_iter) {  // ref :109 / :225
+    const int idx = atomicAdd(a.nxt_count, 1);
+    a.nxt_list[idx] = pair;
+  }
+}
+
+struct LevelInitArgs {
+  int batch, tt, level, nscales;
+  int w_coarse, h_coarse, w_fine, h_fine;  // sizes for zoom_in_parameters (coarse = level+1)
+  double lambda_user, lambda0;
+  double* p;
+  double* lambda_it;
+  double* error;
+  int* niter;
+  int* niter_out;      // [B][nscales]: receives the finished (level+1) counts
+  int* list0; int* counts;  // counts[3]
+};
+
+// Start of a level (ref :106-107, :221-223, :327,:337,:371-372): p from the coarser level through
+// zoom_in_parameters (or zeros / the caller's p at the coarsest level), iteration state reset.
+__global__ void ica_level_init_kernel(LevelInitArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b == 0) { a.counts[0] = a.batch; a.counts[1] = 0; a.counts[2] = 0; }
+  if (b >= a.batch) return;
+  double* p = a.p + (size_t)b * 8;
+  if (a.level == a.nscales - 1) {
+    if (a.nscales > 1)
+      for (int i = 0; i < 8; ++i) p[i] = 0.0;
+    else
+      for (int i = nparams_of(a.tt); i < 8; ++i) p[i] = 0.0;
+  } else {
+    a.niter_out[(size_t)b * a.nscales + a.level + 1] = a.niter[b];
+    zoom_in_parameters(p, a.tt, a.w_coarse, a.h_coarse, a.w_fine, a.h_fine);
+  }
+  a.lambda_it[b] = a.lambda_user > 0.0 ? a.lambda_user : a.lambda0;
+  a.error[b] = 1e10;
+  a.niter[b] = 0;
+  a.list0[b] = b;
+}
+
+__global__ void ica_finish_kernel(int batch, int nscales, const int* niter, const double* error, int* niter_out,
+                                  double* error_out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  niter_out[(size_t)b * nscales] = niter[b];
+  error_out[b] = error[b];
+}
+
+// ---- warp operator (Iw / DI write-out, data generation) -------------------------------------------
+template <int C>
+__global__ __launch_bounds__(kBlock) void ica_warp_kernel(const float* __restrict__ I2, const float* __restrict__ I1,
+                                                          int H, int W, int tt, const double* __restrict__ p,
+                                                          const float* __restrict__ minmax, float* __restrict__ Iw,
+                                                          float* __restrict__ DI) {
+  const int pair = blockIdx.z;
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * kWaves + (threadIdx.x >> 6);
+  if (x >= W || y >= H) return;
+  double ad[8];
+  params_to_displacement(p + (size_t)pair * 8, tt, ad);
+  float A[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) A[i] = (float)ad[i];
+  float dx, dy;
+  if (tt == ICA_HOMOGRAPHY) displacement<true>(A, (float)x, (float)y, dx, dy);
+  else displacement<false>(A, (float)x, (float)y, dx, dy);
+  const size_t plane = (size_t)H * W;
+  const size_t base = (size_t)pair * C * plane;
+  float v[C];
+  const bool ok = warp_sample<C>(I2 + base, H, W, x, y, dx, dy, minmax[pair * 2], minmax[pair * 2 + 1], v);
+  const float nanv = __builtin_nanf("");
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const size_t o = base + c * plane + (size_t)y * W + x;
+    const float iw = ok ? v[c] : nanv;
+    if (Iw) Iw[o] = iw;
+    if (DI) DI[o] = iw - I1[o];
+  }
+}
+
+// ---- min / max of each image ----------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void ica_minmax_partial_kernel(const float* __restrict__ img, size_t elems,
+                                                                    int chunks, float* __restrict__ part) {
+  const int pair = blockIdx.y, chunk = blockIdx.x;
+  const float* q = img + (size_t)pair * elems;
+  const size_t per = (elems + chunks - 1) / chunks;
+  const size_t beg = (size_t)chunk * per, end = min(elems, beg + per);
+  float lo = INFINITY, hi = -INFINITY;
+  for (size_t i = beg + threadIdx.x; i < end; i += kBlock) {
+    const float v = q[i];
+    lo = fminf(lo, v);
+    hi = fmaxf(hi, v);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    lo = fminf(lo, __shfl_down(lo, off, 64));
+    hi = fmaxf(hi, __shfl_down(hi, off, 64));
+  }
+  __shared__ float slo[kWaves], shi[kWaves];
+  if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kWaves; ++w) { lo = fminf(lo, slo[w]); hi = fmaxf(hi, shi[w]); }
+    part[((size_t)pair * chunks + chunk) * 2] = lo;
+    part[((size_t)pair * chunks + chunk) * 2 + 1] = hi;
+  }
+}
+
+__global__ void ica_minmax_final_kernel(const float* __restrict__ part, int chunks, int batch, float* __restrict__ out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  float lo = INFINITY, hi = -INFINITY;
+  for (int c = 0; c < chunks; ++c) {
+    lo = fminf(lo, part[((size_t)b * chunks + c) * 2]);
+    hi = fmaxf(hi, part[((size_t)b * chunks + c) * 2 + 1]);
+  }
+  out[b * 2] = lo;
+  out[b * 2 + 1] = hi;
+}
+
+// ---- per-operator hooks -----------------------------------------------------------------------------
+__global__ void ica_gather_normal_equations_kernel(const double* partials, int tiles, int n, int batch, int have_b,
+                                                   int have_h, const double* Hsetup_partials, double* Hout,
+                                                   double* bout) {
+  __shared__ double s[kAccStride];
+  const int pair = blockIdx.x;
+  gather_partials(partials, pair, tiles, s);
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < 8; ++i) bout[(size_t)pair * 8 + i] = (have_b && i < n) ? s[i] : 0.0;
+    if (have_h) {
+      for (int i = 0; i < 64; ++i) Hout[(size_t)pair * 64 + i] = 0.0;
+      for (int k = 0; k < n; ++k)
+        for (int m = k; m < n; ++m)
+          Hout[(size_t)pair * 64 + k * 8 + m] = Hout[(size_t)pair * 64 + m * 8 + k] = s[kMaxN + tri_index(k, m, n)];
+    }
+  }
+}
+
+__global__ void ica_solve_update_kernel(int batch, int tt, int flags, const double* H, const double* b, double* p,
+                                        double* dp_out, double* err_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= batch) return;
+  const int n = nparams_of(tt);
+  double Hi[64];
+  lu_inverse(n, H + (size_t)i * 64, Hi, 8);
+  double dp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, e2 = 0.0;
+  for (int r = 0; r < n; ++r) {
+    double v = 0.0;
+    for (int c = 0; c < n; ++c) v += Hi[r * 8 + c] * b[(size_t)i * 8 + c];
+    dp[r] = v;
+    e2 += v * v;
+  }
+  update_transform(p + (size_t)i * 8, dp, tt, (flags & ICA_FLAG_EXACT_UPDATE) != 0);
+  if (dp_out)
+    for (int r = 0; r < 8; ++r) dp_out[(size_t)i * 8 + r] = dp[r];
+  if (err_out) err_out[i] = sqrt(e2);
+}
+
+__global__ void ica_zoom_params_kernel(int batch, int tt, int w, int h, int ww, int hh, double* p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < batch) zoom_in_parameters(p + (size_t)i * 8, tt, w, h, ww, hh);
+}
+
+// ---- pyramid: separable banded resampling (Gaussian + B-spline prefilter + zoom folded into one
+//      operator per axis on the host, see ica_pyramid.hpp) ------------------------------------------
+struct BandOp {
+  const int* start;    // [n_out] first input index of the band
+  const double* w;     // [n_out][K]
+  int n_in, n_out, K;
+};
+
+// out[b][c][y][o] = sum_k w[o][k] * in[b][c][y][start[o]+k]
+__global__ __launch_bounds__(kBlock) void ica_resample_x_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                int planes, int H, BandOp op) {
+  const int o = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * kWaves + (threadIdx.x >> 6);
+  const int pl = blockIdx.z;
+  if (o >= op.n_out || y >= H || pl >= planes) return;
+  const float* row = in + ((size_t)pl * H + y) * op.n_in;
+  const int s = op.start[o];
+  const double* w = op.w + (size_t)o * op.K;
+  double acc = 0.0;
+  for (int k = 0; k < op.K; ++k) {
+    const int j = s + k;
+    if (j >= 0 && j < op.n_in) acc += w[k] * (double)row[j];
+  }
+  out[((size_t)pl * H + y) * op.n_out + o] = (float)acc;
+}
+
+// out[b][c][o][x] = clip(sum_k w[o][k] * in[b][c][start[o]+k][x], minmax of the pair)
+__global__ __launch_bounds__(kBlock) void ica_resample_y_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                int planes, int channels, int W, BandOp op,
+                                                                const float* __restrict__ minmax) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int o = blockIdx.y * kWaves + (threadIdx.x >> 6);
+  const int pl = blockIdx.z;
+  if (x >= W || o >= op.n_out || pl >= planes) return;
+  const float* col = in + (size_t)pl * op.n_in * W + x;
+  const int s = op.start[o];
+  const double* w = op.w + (size_t)o * op.K;
+  double acc = 0.0;
+  for (int k = 0; k < op.K; ++k) {
+    const int j = s + k;
+    if (j >= 0 && j < op.n_in) acc += w[k] * (double)col[(size_t)j * W];
+  }
+  const int pair = pl / channels;
+  const float v = fminf(fmaxf((float)acc, minmax[pair * 2]), minmax[pair * 2 + 1]);
+  out[((size_t)pl * op.n_out + o) * W + x] = v;
+}
+
+}  // namespace ica

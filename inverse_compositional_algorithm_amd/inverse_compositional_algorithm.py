@@ -1,0 +1,106 @@
+"""Drop-in for the reference's ``src/inverse_compositional_algorithm.py``: same three functions, same
+keyword names, same return tuple ``(p, error, DI, Iw)``, same ValueErrors -- computed on an MI355X by
+libica_hip.so.  There is no CPU path here: without the HIP library / a GPU these functions raise.
+
+reference: inverse_compositional_algorithm.py:17-133, :135-261, :264-374
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import constants as cts
+from .engine import IcaEngine
+from .image_optimisation import RobustErrorFunctionType
+from .transformation import TransformType
+
+_ENGINES: dict = {}
+_RGB_MSG = "I1 and I2 must be RGB images with channels in the last dimension"
+_DIM_MSG = "I1 and I2 must have the same dimensions"
+_TOL_MSG = "TOL must be positive and very small (less than 0.01)"
+
+
+def _engine(device: int = 0) -> IcaEngine:
+    if device not in _ENGINES:
+        _ENGINES[device] = IcaEngine(device)
+    return _ENGINES[device]
+
+
+def _to_device(img: np.ndarray, eng: IcaEngine) -> torch.Tensor:
+    a = np.ascontiguousarray(np.moveaxis(np.asarray(img, dtype=np.float32), 2, 0))[None]
+    return torch.from_numpy(a).to(eng.device)
+
+
+def _to_host(t: torch.Tensor) -> np.ndarray:
+    return np.moveaxis(t[0].cpu().numpy().astype(np.float64), 0, 2)
+
+
+def _print_trace(trace, niter, nparams, nscales, robust, pyramidal, robust_type):
+    # reference: :125-129 (L2), :253-257 (robust), :341-345,:357-358 (pyramid headers)
+    for s in range(nscales - 1, -1, -1):
+        if pyramidal:
+            print(f"Scale: {s}")
+            print("(L2 norm)" if not robust else f"(Robust error function {robust_type})")
+        for it in range(int(niter[s])):
+            row = trace[s, it]
+            ps = " ".join(repr(float(v)) for v in row[1:1 + nparams])
+            if robust:
+                print(f"|Dp|={float(row[0])}: p=({ps}), lambda_={float(row[9])}")
+            else:
+                print(f"Iteration {it}: |Dp|={float(row[0])}: p=({ps})")
+
+
+def _run(I1, I2, p, transform_type, TOL, robust_type, lambda_, nanifoutside, delta, verbose, nscales, nu,
+         need_rgb, pyramidal):
+    I1 = np.asarray(I1)
+    I2 = np.asarray(I2)
+    if need_rgb and (I1.ndim != 3 or I2.ndim != 3 or I1.shape[2] != 3 or I2.shape[2] != 3):
+        raise ValueError(_RGB_MSG)                                     # ref :48-49, :300-301
+    if I1.ndim != 3:
+        raise ValueError("not enough values to unpack (expected 3, got %d)" % I1.ndim)  # ref :169 unpack
+    if I1.shape != I2.shape:
+        raise ValueError(_DIM_MSG)                                     # ref :55-56
+    if TOL >= 0.01:
+        raise ValueError(_TOL_MSG)                                     # ref :59-60
+    if I1.shape[2] not in (1, 3):
+        raise ValueError(_RGB_MSG)
+    tt = TransformType(transform_type) if not isinstance(transform_type, TransformType) else transform_type
+    rt = RobustErrorFunctionType(robust_type) if not isinstance(robust_type, RobustErrorFunctionType) else robust_type
+    n = tt.nparams()
+    eng = _engine()
+    H, W, C = I1.shape
+    prob = eng.problem(1, H, W, C, tt.value, rt.value, nscales, nu, TOL, float(lambda_), bool(nanifoutside is True),
+                       int(delta), cts.MAX_ITER)
+    p0 = torch.as_tensor(np.asarray(p, dtype=np.float64)[:n]).reshape(1, n)
+    res = eng.solve(_to_device(I1, eng), _to_device(I2, eng), prob, p0=p0, want_images=True, want_trace=bool(verbose))
+    p_out = res.p[0, :n].cpu().numpy()
+    error = float(res.error[0].cpu())
+    if verbose:
+        _print_trace(res.trace[0].cpu().numpy(), res.niter[0].cpu().numpy(), n, nscales,
+                     rt != RobustErrorFunctionType.QUADRATIC, pyramidal, rt)
+    if isinstance(p, np.ndarray) and p.dtype == np.float64 and p.shape[0] >= n:
+        p[:n] = p_out      # the reference mutates the caller's array (transformation.py:54,68-70,...)
+        if not pyramidal:
+            p_out = p
+    return p_out, error, _to_host(res.DI), _to_host(res.Iw)
+
+
+def inverse_compositional_algorithm(I1, I2, p, transform_type, TOL, nanifoutside, delta, verbose):
+    """Quadratic (L2) inverse compositional algorithm.  reference: :17-133"""
+    return _run(I1, I2, p, transform_type, TOL, RobustErrorFunctionType.QUADRATIC, 0.0, nanifoutside, delta, verbose,
+                1, 0.5, need_rgb=True, pyramidal=False)
+
+
+def robust_inverse_compositional_algorithm(I1, I2, p, transform_type, TOL, robust_type, lambda_, nanifoutside, delta,
+                                           verbose):
+    """Robust inverse compositional algorithm.  reference: :135-261.  Like the reference, this entry point runs
+    the robust loop even for QUADRATIC (rho' = 1, Hessian re-inverted every iteration)."""
+    return _run(I1, I2, p, transform_type, TOL, robust_type, lambda_, nanifoutside, delta, verbose, 1, 0.5,
+                need_rgb=False, pyramidal=False)
+
+
+def pyramidal_inverse_compositional_algorithm(I1, I2, p, transform_type, nscales, nu, TOL, robust_type, lambda_,
+                                              nanifoutside, delta, verbose):
+    """Coarse-to-fine driver.  reference: :264-374"""
+    return _run(I1, I2, p, transform_type, TOL, robust_type, lambda_, nanifoutside, delta, verbose, int(nscales),
+                float(nu), need_rgb=True, pyramidal=True)

@@ -1,0 +1,98 @@
+"""Host-side mirror of the reference's ``transformation`` module (reference: src/transformation.py).
+
+Only the 8-number algebra lives here (NumPy, float64); image warping runs on the GPU.
+"""
+from __future__ import annotations
+
+import math
+from enum import Enum
+
+import numpy as np
+
+
+class TransformType(Enum):
+    """reference: transformation.py:8-13"""
+    TRANSLATION = 1
+    EUCLIDEAN = 2
+    SIMILARITY = 3
+    AFFINITY = 4
+    HOMOGRAPHY = 5
+
+    def nparams(self) -> int:
+        """reference: transformation.py:16-32"""
+        return {1: 2, 2: 3, 3: 4, 4: 6, 5: 8}[self.value]
+
+
+def _tt(transform_type) -> int:
+    return transform_type.value if isinstance(transform_type, Enum) else int(transform_type)
+
+
+def params2matrix(p, transform_type) -> np.ndarray:
+    """reference: transformation.py:188-236"""
+    t = _tt(transform_type)
+    m = np.identity(3)
+    if t == 1:
+        m[0, 2], m[1, 2] = p[0], p[1]
+    elif t == 2:
+        c, s = math.cos(p[2]), math.sin(p[2])
+        m[0, :], m[1, :] = (c, -s, p[0]), (s, c, p[1])
+    elif t == 3:
+        m[0, :], m[1, :] = (1 + p[2], -p[3], p[0]), (p[3], 1 + p[2], p[1])
+    elif t == 4:
+        m[0, :], m[1, :] = (1 + p[2], p[3], p[0]), (p[4], 1 + p[5], p[1])
+    elif t == 5:
+        m[0, :], m[1, :], m[2, :2] = (1 + p[0], p[1], p[2]), (p[3], 1 + p[4], p[5]), (p[6], p[7])
+    return m
+
+
+def matrix2params(matrix, transform_type):
+    """reference: transformation.py:238-263 (returns a list, as the reference does)."""
+    t = _tt(transform_type)
+    m = matrix
+    if t == 1:
+        return [m[0, 2], m[1, 2]]
+    if t == 2:
+        return [m[0, 2], m[1, 2], np.arctan2(m[1, 0], m[0, 0])]
+    if t == 3:
+        return [m[0, 2], m[1, 2], m[0, 0] - 1, m[1, 0]]
+    if t == 4:
+        return [m[0, 2], m[1, 2], m[0, 0] - 1, m[0, 1], m[1, 0], m[1, 1] - 1]
+    if t == 5:
+        return [m[0, 0] - 1, m[0, 1], m[0, 2], m[1, 0], m[1, 1] - 1, m[1, 2], m[2, 0], m[2, 1]]
+    return np.zeros(0)
+
+
+def update_transform(p: np.ndarray, dp: np.ndarray, transform_type, exact: bool = False) -> np.ndarray:
+    """p <- params(M(p) . M(dp)^-1), in place and returned (reference: transformation.py:35-141).
+
+    Host twin of the device routine in csrc/ica_math.hpp (same construction: 3x3 composition through
+    the adjugate plus the reference's two scalar-formula deviations unless ``exact``)."""
+    t = _tt(transform_type)
+    if t == 1:
+        p[:2] -= dp[:2]
+        return p
+    P, A = params2matrix(p, t), params2matrix(dp, t)
+    adj = np.linalg.inv(A) * np.linalg.det(A)
+    m = P @ adj
+    if t == 2:
+        p[0], p[1], p[2] = m[0, 2], m[1, 2], math.atan2(m[1, 0], m[0, 0])
+    elif t == 3:
+        det = A[0, 0] ** 2 + A[1, 0] ** 2
+        if det * det > 1e-10:
+            p[:] = [m[0, 2] / det, m[1, 2] / det, m[0, 0] / det - 1, m[1, 0] / det]
+    elif t == 4:
+        det = A[0, 0] * A[1, 1] - A[0, 1] * A[1, 0]
+        if det * det > 1e-10:
+            ep, c, d = p[5], dp[0], dp[4]
+            p[:] = [m[0, 2] / det, m[1, 2] / det, m[0, 0] / det - 1, m[0, 1] / det, m[1, 0] / det, m[1, 1] / det - 1]
+            if not exact:
+                p[1] += (d * d * ep - c * d * ep) / det
+    elif t == 5:
+        det = -m[2, 2]
+        if det * det > 1e-10:
+            a, c, g = dp[0], dp[2], dp[6]
+            m = m / m[2, 2]
+            p[:] = [m[0, 0] - 1, m[0, 1], m[0, 2], m[1, 0], m[1, 1] - 1, m[1, 2], m[2, 0], m[2, 1]]
+            if not exact:
+                p[4] -= (-a + c * g) / det
+    return p

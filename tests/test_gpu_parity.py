@@ -1,0 +1,217 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle on the same seeded inputs.
+
+Tolerances.  The reference computes in float64; the kernels compute per-pixel quantities in float32
+and accumulate / solve in float64.  north_star's bar: recovered parameters within 1e-4 relative.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+from oracle import ica_oracle as oc  # noqa: E402
+from inverse_compositional_algorithm_amd import synthetic as syn  # noqa: E402
+
+TYPES = [oc.TRANSLATION, oc.EUCLIDEAN, oc.SIMILARITY, oc.AFFINITY, oc.HOMOGRAPHY]
+P_REL_TOL = 1e-4        # north_star: recovered parameters within 1e-4 relative
+CORNER_TOL_PX = 1e-3    # max corner displacement between the two solutions
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from inverse_compositional_algorithm_amd.engine import IcaEngine
+    return IcaEngine(0)
+
+
+def to_dev(eng, *imgs):
+    """(H,W,C) numpy -> [1,C,H,W] float32 device tensors (batched along dim 0)."""
+    a = np.stack([np.moveaxis(np.asarray(i, dtype=np.float32), 2, 0) for i in imgs])
+    return torch.from_numpy(np.ascontiguousarray(a)).to(eng.device)
+
+
+def to_np(t):
+    return np.moveaxis(t.cpu().numpy().astype(np.float64), 1, 3)  # [B,H,W,C]
+
+
+def corners_disp(p, q, t, H, W):
+    Mp, Mq = oc.params2matrix(p, t), oc.params2matrix(q, t)
+    d = 0.0
+    for x, y in ((0, 0), (W - 1, 0), (0, H - 1), (W - 1, H - 1)):
+        a = Mp @ [x, y, 1.0]
+        b = Mq @ [x, y, 1.0]
+        d = max(d, float(np.hypot(a[0] / a[2] - b[0] / b[2], a[1] / a[2] - b[1] / b[2])))
+    return d
+
+
+def pairs(t, n, H=96, W=128, C=3, clutter=False, seed0=500):
+    out = [syn.make_pair(seed0 + 17 * t + i, H, W, C, t, robust_clutter=clutter) for i in range(n)]
+    return [o[0] for o in out], [o[1] for o in out], [o[2] for o in out]
+
+
+@pytest.mark.parametrize("t", TYPES)
+@pytest.mark.parametrize("C", [1, 3])
+def test_warp_operator(eng, t, C):
+    """ica_op_warp_dev vs oracle.warp_params (bicubic_interpolation.py:154-206)."""
+    I1s, I2s, pg = pairs(t, 3, C=C)
+    ps = [g * s for g, s in zip(pg, (1.0, -0.7, 2.5))] + [np.zeros(oc.nparams(t))]
+    I2s, I1s = I2s + [I2s[0]], I1s + [I1s[0]]
+    p = np.zeros((4, 8))
+    for i, q in enumerate(ps):
+        p[i, :len(q)] = q
+    Iw, DI = eng.warp(to_dev(eng, *I2s), torch.from_numpy(p), t, I1=to_dev(eng, *I1s))
+    Iw, DI = to_np(Iw), to_np(DI)
+    for i in range(4):
+        want = oc.warp_params(I2s[i].astype(np.float64), ps[i], t)
+        assert np.array_equal(np.isnan(Iw[i]), np.isnan(want)), "NaN (out-of-image) mask differs"
+        np.testing.assert_allclose(np.nan_to_num(Iw[i]), np.nan_to_num(want), atol=2e-3)
+        np.testing.assert_allclose(np.nan_to_num(DI[i]), np.nan_to_num(want - I1s[i]), atol=2e-3)
+
+
+def test_minmax(eng):
+    x = torch.randn(5, 3, 37, 91, device=eng.device)
+    mm = eng.minmax(x).cpu().numpy()
+    np.testing.assert_array_equal(mm[:, 0], x.amin(dim=(1, 2, 3)).cpu().numpy())
+    np.testing.assert_array_equal(mm[:, 1], x.amax(dim=(1, 2, 3)).cpu().numpy())
+
+
+@pytest.mark.parametrize("t", TYPES)
+@pytest.mark.parametrize("r", [oc.QUADRATIC, oc.LORENTZIAN])
+@pytest.mark.parametrize("C", [1, 3])
+def test_normal_equations(eng, t, r, C):
+    """H and b of one iteration vs the oracle's materialised-tensor einsums."""
+    I1s, I2s, pg = pairs(t, 2, C=C, clutter=(r != 0))
+    n = oc.nparams(t)
+    H_, W_ = I1s[0].shape[:2]
+    prob = eng.problem(2, H_, W_, C, t, r, delta=5)
+    p = np.zeros((2, 8))
+    p[0, :n] = pg[0] * 0.6
+    lam = 37.0
+    Hm, bv = eng.normal_equations(to_dev(eng, *I1s), to_dev(eng, *I2s), torch.from_numpy(p), prob, lambda_it=lam)
+    Hm, bv = Hm.cpu().numpy(), bv.cpu().numpy()
+    for i in range(2):
+        I1, I2 = I1s[i].astype(np.float64), I2s[i].astype(np.float64)
+        Ix, Iy = oc.gradient(I1, True, 5)
+        DIJ = oc.steepest_descent_images(Ix, Iy, oc.jacobian(t, W_, H_), n)
+        DI = oc.warp_params(I2, p[i, :n], t) - I1
+        rho = oc.robust_error_function(DI, lam, r) if r else None
+        Hw, bw = oc.hessian(DIJ, rho), oc.independent_vector(DIJ, DI, rho)
+        sc = np.sqrt(np.diag(Hw))
+        np.testing.assert_allclose(Hm[i, :n, :n] / np.outer(sc, sc), Hw / np.outer(sc, sc), atol=2e-6)
+        # b is a cancelling sum: compare against the scale sum|terms| ~ sc * |DI|_2
+        bscale = sc * np.sqrt(np.nansum((DI * (np.sqrt(rho)[..., None] if r else 1.0)) ** 2))
+        np.testing.assert_allclose(bv[i, :n] / bscale, bw / bscale, atol=5e-6)
+        assert np.all(Hm[i, n:, :] == 0) and np.all(bv[i, n:] == 0)
+
+
+@pytest.mark.parametrize("t", TYPES)
+def test_solve_update_operator(eng, t):
+    rng = np.random.default_rng(t)
+    n = oc.nparams(t)
+    B = 16
+    H = np.zeros((B, 8, 8))
+    b = np.zeros((B, 8))
+    p = np.zeros((B, 8))
+    sc = np.ones(n)
+    if t == oc.HOMOGRAPHY:
+        sc[[2, 5]], sc[[6, 7]] = 30.0, 1e-3
+    for i in range(B):
+        A = rng.normal(size=(n + 3, n)) / sc
+        H[i, :n, :n] = A.T @ A
+        b[i, :n] = rng.normal(size=n) / sc * 0.05
+        p[i, :n] = rng.normal(size=n) * sc * 0.05
+    H[0] = 0.0  # singular -> H^-1 = 0 -> dp = 0 (derivatives.py:125-130)
+    pn, dp, err = eng.solve_update(torch.from_numpy(H), torch.from_numpy(b), torch.from_numpy(p), t)
+    pn, dp, err = pn.cpu().numpy(), dp.cpu().numpy(), err.cpu().numpy()
+    for i in range(B):
+        e_w, dp_w = oc.parametric_solve(oc.inverse_hessian(H[i, :n, :n]), b[i, :n])
+        p_w = oc.update_transform(p[i, :n].copy(), dp_w, t)
+        np.testing.assert_allclose(dp[i, :n], dp_w, rtol=1e-9, atol=1e-300)
+        np.testing.assert_allclose(err[i], e_w, rtol=1e-9)
+        np.testing.assert_allclose(pn[i, :n], p_w, rtol=1e-9, atol=1e-14)
+    assert err[0] == 0.0 and np.allclose(pn[0], p[0], rtol=1e-14, atol=0)
+
+
+@pytest.mark.parametrize("shape", [(96, 128), (135, 101), (68, 120)])
+@pytest.mark.parametrize("C", [1, 3])
+def test_pyramid_down(eng, shape, C):
+    """ica_op_pyramid_down_dev vs the restated skimage.rescale (ref :333-336)."""
+    H_, W_ = shape
+    rng = np.random.default_rng(H_ + C)
+    imgs = [np.round(rng.uniform(0, 255, (H_, W_, C))) for _ in range(2)]
+    got = to_np(eng.pyramid_down(to_dev(eng, *imgs), 0.5))
+    for i in range(2):
+        want = oc.rescale_restated(imgs[i], 0.5)
+        assert got[i].shape == want.shape
+        np.testing.assert_allclose(got[i], want, atol=1e-4)
+
+
+def test_zoom_in_parameters(eng):
+    for t in TYPES:
+        p = np.zeros((3, 8))
+        p[:, :oc.nparams(t)] = np.random.default_rng(t).normal(size=(3, oc.nparams(t)))
+        got = eng.zoom_in_parameters(torch.from_numpy(p), t, 68, 120, 135, 240).cpu().numpy()
+        for i in range(3):
+            np.testing.assert_allclose(got[i, :oc.nparams(t)],
+                                       oc.zoom_in_parameters(p[i, :oc.nparams(t)], t, 68, 120, 135, 240), rtol=1e-15)
+
+
+CASES = [(oc.TRANSLATION, oc.QUADRATIC, 1, 3), (oc.EUCLIDEAN, oc.QUADRATIC, 2, 3), (oc.SIMILARITY, oc.CHARBONNIER, 1, 3),
+         (oc.AFFINITY, oc.QUADRATIC, 2, 1), (oc.AFFINITY, oc.GERMAN_MCCLURE, 2, 3), (oc.HOMOGRAPHY, oc.QUADRATIC, 2, 1),
+         (oc.HOMOGRAPHY, oc.LORENTZIAN, 2, 3), (oc.HOMOGRAPHY, oc.CHARBONNIER, 1, 1),
+         (oc.AFFINITY, oc.TRUNCATED_QUADRATIC, 1, 1)]
+
+
+@pytest.mark.parametrize("t,r,ns,C", CASES)
+def test_full_solve_matches_oracle(eng, t, r, ns, C):
+    """Whole pyramidal solve, iteration by iteration, against the oracle on the same inputs."""
+    B = 3
+    I1s, I2s, _ = pairs(t, B, H=128, W=160, C=C, clutter=(r != 0), seed0=900 + r)
+    n = oc.nparams(t)
+    prob = eng.problem(B, 128, 160, C, t, r, nscales=ns, nu=0.5, tol=1e-3, lambda_=0.0, delta=5)
+    res = eng.solve(to_dev(eng, *I1s), to_dev(eng, *I2s), prob, want_images=True, want_trace=True, want_stats=True)
+    p, err, nit, tr = res.p.cpu().numpy(), res.error.cpu().numpy(), res.niter.cpu().numpy(), res.trace.cpu().numpy()
+    Iw, DI = to_np(res.Iw), to_np(res.DI)
+    total = 0
+    for i in range(B):
+        traces = []
+        p_w, e_w, DI_w, Iw_w, nit_w = oc.ica_pyramidal(I1s[i].astype(np.float64), I2s[i].astype(np.float64), np.zeros(n),
+                                                       t, ns, 0.5, 1e-3, r, 0.0, True, 5, traces=traces)
+        assert list(nit[i]) == list(nit_w), f"iterations per scale differ: {nit[i]} vs {nit_w}"
+        total += sum(nit_w)
+        rel = np.linalg.norm(p[i, :n] - p_w) / np.linalg.norm(p_w)
+        assert rel <= P_REL_TOL, f"pair {i}: relative parameter error {rel:.2e}"
+        assert corners_disp(p[i, :n], p_w, t, 128, 160) <= CORNER_TOL_PX
+        np.testing.assert_allclose(err[i], e_w, rtol=2e-2, atol=1e-6)
+        for s, trs in traces:  # per-iteration trace parity
+            for k, itd in enumerate(trs):
+                row = tr[i, s, k]
+                assert corners_disp(row[1:1 + n], itd["p"], t, *[(128, 160), (64, 80)][s]) <= 5e-3
+                if r:
+                    np.testing.assert_allclose(row[9], itd["lam"], rtol=1e-12)
+        assert np.array_equal(np.isnan(Iw[i]), np.isnan(Iw_w))
+        np.testing.assert_allclose(np.nan_to_num(Iw[i]), np.nan_to_num(Iw_w), atol=2e-2)
+        np.testing.assert_allclose(np.nan_to_num(DI[i]), np.nan_to_num(DI_w), atol=2e-2)
+    assert res.stats["pair_iterations_total"] == total
+
+
+def test_initial_p_used_only_for_single_scale(eng):
+    """ref :327,:337,:372 -- with nscales > 1 the caller's p is discarded."""
+    t = oc.AFFINITY
+    I1s, I2s, pg = pairs(t, 1, H=128, W=160, C=1)
+    d1, d2 = to_dev(eng, *I1s), to_dev(eng, *I2s)
+    p0 = torch.from_numpy(pg[0][None] * 0.9)
+    a = eng.solve(d1, d2, eng.problem(1, 128, 160, 1, t, nscales=1), p0=p0)
+    b = eng.solve(d1, d2, eng.problem(1, 128, 160, 1, t, nscales=1))
+    assert int(a.niter[0, 0]) < int(b.niter[0, 0])
+    c = eng.solve(d1, d2, eng.problem(1, 128, 160, 1, t, nscales=2), p0=p0)
+    d = eng.solve(d1, d2, eng.problem(1, 128, 160, 1, t, nscales=2))
+    assert torch.equal(c.p, d.p)
+
+
+def test_deterministic(eng):
+    t = oc.HOMOGRAPHY
+    I1s, I2s, _ = pairs(t, 4, H=128, W=160, C=3, clutter=True)
+    d1, d2 = to_dev(eng, *I1s), to_dev(eng, *I2s)
+    prob = eng.problem(4, 128, 160, 3, t, oc.LORENTZIAN, nscales=2)
+    a, b = eng.solve(d1, d2, prob), eng.solve(d1, d2, prob)
+    assert torch.equal(a.p, b.p) and torch.equal(a.niter, b.niter)
