@@ -67,6 +67,10 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm wheels carry their own libamdhip64.so.7 / libhsa-runtime64.so.1 (same SONAMEs as /opt/rocm).
+    # A process must end up with ONE HIP runtime, shared by torch (device memory, streams) and this library,
+    # so torch's copy has to be mapped before libica_hip.so asks the loader for that SONAME.
+    import torch  # noqa: F401
     if not os.path.isfile(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} is missing: the HIP extension has not been built (python -m "

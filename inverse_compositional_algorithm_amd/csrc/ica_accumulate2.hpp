@@ -1,0 +1,510 @@
+// Fused per-iteration pass, LDS-staged + double-buffered (the production kernel).
+//
+// One workgroup (4 waves) owns a 64-column x tile_h-row tile of one image pair and walks it in chunks of
+// CH rows.  For every chunk:
+//   1. The footprint of the chunk under the current warp is the convex quadrilateral of its 4 mapped
+//      corners; its bounding box (+ bicubic halo) of I2 and the chunk (+1-px halo) of I1 are moved
+//      HBM/L2 -> LDS by LDS-DMA (global_load_lds, 16 B per lane, no VGPRs).  The copy for chunk k+1 is issued
+//      right after the barrier that publishes chunk k, so it runs underneath chunk k's arithmetic
+//      (two LDS buffers, one barrier per chunk).  A footprint that does not fit the buffer falls back to
+//      direct cached gathers for that chunk -- same arithmetic, same results.
+//   2. Each lane owns one image column; each wave walks RW consecutive rows.  All 16 bicubic taps and the
+//      5-point gradient stencil come from LDS with compile-time offsets; nothing but the two images is ever
+//      read from memory (the reference materialises 192 B/pixel of gradient/Jacobian/steepest-descent tensors).
+//   3. "Moment" accumulation.  Every Jacobian entry is a monomial c*x^a*y^b (derivatives.py:33-68), so
+//        b_k  = sum_pix (Jx_k Gx + Jy_k Gy),                 Gx = rho' * sum_c Ix_c DI_c, Gy likewise
+//        H_km = sum_pix (Jx_k Jx_m Sxx + (Jx_k Jy_m + Jy_k Jx_m) Sxy + Jy_k Jy_m Syy),  Sxx = rho' sum_c Ix_c^2 ...
+//      x^a is constant per lane and factors out of the row loop: per pixel only the y-moments
+//      sum_y y^b G* and sum_y y^b S** are accumulated (4 FMAs for affine L2 instead of 6 products + 6 FMAs;
+//      12 + 5 instead of (36 + 8 + 8) * C for robust homography, independent of C).  The x powers are applied
+//      once per tile, in fp64, when the 64 lanes' moments are folded into the <= 44 sums.
+//   fp32 per pixel, promoted to fp64 after every wave band; fixed summation order throughout (deterministic).
+#pragma once
+#include "ica_kernels.hpp"
+
+namespace ica {
+
+struct Mono { signed char c, a, b; };  // c * x^a * y^b; c == 0: structurally zero
+
+// Jacobian rows dW/dp (derivatives.py:33-68) as monomials; jac_x(tt, k) = dx'/dp_k, jac_y(tt, k) = dy'/dp_k
+__host__ __device__ constexpr Mono jac_x(int tt, int k) {
+  constexpr Mono Z{0, 0, 0}, ONE{1, 0, 0}, X{1, 1, 0}, Y{1, 0, 1}, NY{-1, 0, 1}, NXX{-1, 2, 0}, NXY{-1, 1, 1};
+  switch (tt) {
+    case ICA_TRANSLATION: return k == 0 ? ONE : Z;
+    case ICA_EUCLIDEAN: return k == 0 ? ONE : k == 2 ? NY : Z;
+    case ICA_SIMILARITY: return k == 0 ? ONE : k == 2 ? X : k == 3 ? NY : Z;
+    case ICA_AFFINITY: return k == 0 ? ONE : k == 2 ? X : k == 3 ? Y : Z;
+    case ICA_HOMOGRAPHY: return k == 0 ? X : k == 1 ? Y : k == 2 ? ONE : k == 6 ? NXX : k == 7 ? NXY : Z;
+    default: return Z;
+  }
+}
+__host__ __device__ constexpr Mono jac_y(int tt, int k) {
+  constexpr Mono Z{0, 0, 0}, ONE{1, 0, 0}, X{1, 1, 0}, Y{1, 0, 1}, NXY{-1, 1, 1}, NYY{-1, 0, 2};
+  switch (tt) {
+    case ICA_TRANSLATION: return k == 1 ? ONE : Z;
+    case ICA_EUCLIDEAN: return k == 1 ? ONE : k == 2 ? X : Z;
+    case ICA_SIMILARITY: return k == 1 ? ONE : k == 2 ? Y : k == 3 ? X : Z;
+    case ICA_AFFINITY: return k == 1 ? ONE : k == 4 ? X : k == 5 ? Y : Z;
+    case ICA_HOMOGRAPHY: return k == 3 ? X : k == 4 ? Y : k == 5 ? ONE : k == 6 ? NXY : k == 7 ? NYY : Z;
+    default: return Z;
+  }
+}
+
+// highest y power among the Jx (mbx) / Jy (mby) entries of each transform
+template <int TT> struct MomShape;
+template <> struct MomShape<ICA_TRANSLATION> { static constexpr int mbx = 0, mby = 0; };
+template <> struct MomShape<ICA_EUCLIDEAN> { static constexpr int mbx = 1, mby = 0; };
+template <> struct MomShape<ICA_SIMILARITY> { static constexpr int mbx = 1, mby = 1; };
+template <> struct MomShape<ICA_AFFINITY> { static constexpr int mbx = 1, mby = 1; };
+template <> struct MomShape<ICA_HOMOGRAPHY> { static constexpr int mbx = 1, mby = 2; };
+
+template <int TT> struct MomLayout {
+  static constexpr int mbx = MomShape<TT>::mbx, mby = MomShape<TT>::mby;
+  static constexpr int ngx = mbx + 1, ngy = mby + 1, nxx = 2 * mbx + 1, nxy = mbx + mby + 1, nyy = 2 * mby + 1;
+  static constexpr int ogx = 0, ogy = ngx, oxx = ngx + ngy, oxy = oxx + nxx, oyy = oxy + nxy;
+  static constexpr int nmom = oyy + nyy;  // <= 17
+};
+
+template <int C> struct TileCfg {
+  static constexpr int ch = 16;                        // image rows per chunk: 4 waves x 4 rows
+  static constexpr int rw = ch / kWaves;
+  static constexpr int p2 = 96, r2 = 32;               // I2 footprint buffer: pitch (floats) x rows
+  static constexpr int p1 = 72, r1 = ch + 2;           // I1 buffer: columns x_t0-4 .. x_t0+67, rows yc0-1 .. yc0+ch
+  static constexpr int nbuf = (C == 1) ? 2 : 1;        // double buffering where LDS allows 4 workgroups per CU
+  static constexpr int buf_floats = C * (p2 * r2 + p1 * r1);
+};
+
+// 16 bytes per lane, global -> LDS at (wave-uniform) lds_base + 16*lane; 4 bytes per lane for unaligned rows
+__device__ __forceinline__ void glds16(const float* gsrc, float* lds_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+}
+__device__ __forceinline__ void glds4(const float* gsrc, float* lds_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_base, 4, 0, 0);
+}
+
+template <bool PROJ>
+__device__ __forceinline__ void displacement_col(const float* A, float cx, float cy, float gx, float xf, float yf,
+                                                 float& dx, float& dy) {
+  // displacement<>() with the per-column terms (cx = a0 x + a2, cy = a3 x + a5, gx = a6 x) hoisted
+  float nx = fmaf(A[1], yf, cx);
+  float ny = fmaf(A[4], yf, cy);
+  if constexpr (PROJ) {
+    const float g = fmaf(A[7], yf, gx);
+    const float r = 1.0f / (1.0f + g);
+    nx = (nx - xf * g) * r;
+    ny = (ny - yf * g) * r;
+  }
+  dx = nx;
+  dy = ny;
+}
+
+template <int TT, int MODE, int C>
+__global__ __launch_bounds__(kBlock) void ica_accumulate2_kernel(LevelArgs a) {
+  constexpr int N = NP<TT>::n;
+  constexpr int NT = N * (N + 1) / 2;
+  constexpr bool kB = (MODE != kModeHessian);
+  constexpr bool kH = (MODE != kModeL2);
+  constexpr bool kProj = (TT == ICA_HOMOGRAPHY);
+  using ML = MomLayout<TT>;
+  using TC = TileCfg<C>;
+  constexpr int CH = TC::ch, RW = TC::rw, P2 = TC::p2, R2 = TC::r2, P1 = TC::p1, R1 = TC::r1, NBUF = TC::nbuf;
+  constexpr int NMOM = ML::nmom;
+
+  __shared__ __attribute__((aligned(16))) float lds[NBUF * TC::buf_floats];
+  static_assert(sizeof(float) * NBUF * TC::buf_floats >= sizeof(double) * NMOM * 64, "moment scratch must fit");
+
+  int pair = blockIdx.y;
+  if (a.act_list) {
+    if ((int)blockIdx.y >= *a.act_count) return;
+    pair = a.act_list[blockIdx.y];
+  }
+  const int tile_id = blockIdx.x;
+  const int tx = tile_id % a.tiles_x, ty = tile_id / a.tiles_x;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int H = a.H, W = a.W;
+  const size_t plane = (size_t)H * W;
+  const float* I1 = a.I1 + (size_t)pair * C * plane;
+  const float* I2 = a.I2 + (size_t)pair * C * plane;
+
+  float A[8];
+  float lo = 0.f, hi = 0.f, lam2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) A[i] = 0.f;
+  if constexpr (kB) {
+    double ad[8];
+    params_to_displacement(a.p + (size_t)pair * 8, TT, ad);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) A[i] = (float)ad[i];
+    lo = a.minmax[pair * 2];
+    hi = a.minmax[pair * 2 + 1];
+    if constexpr (MODE == kModeRobust) {
+      const float l = (float)a.lambda_it[pair];
+      lam2 = l * l;
+    }
+  }
+
+  const int x_t0 = tx * kTileW;
+  const int x = x_t0 + lane;
+  const float xf = (float)x;
+  const int y_begin = ty * a.tile_h;
+  const int y_end = min(H, y_begin + a.tile_h);
+  const int nchunks = (y_end - y_begin + CH - 1) / CH;  // <= 64: one lane plans one chunk (tile_h <= 1024)
+  const bool frame_on = a.nanif && a.delta > 0;
+  const bool col_ok = (x < W) & !(frame_on & ((x < a.delta) | (x >= W - a.delta)));
+  const bool col_inner = (x >= 1) & (x <= W - 2);       // ref :81: the 1-px border keeps a zero x-derivative
+  const float cx = fmaf(A[0], xf, A[2]), cy = fmaf(A[3], xf, A[5]), gxc = A[6] * xf;
+  const float vx_lo = (float)(1 - x), vx_hi = (float)(W - 3 - x);
+  const bool w4 = (W & 3) == 0;                         // rows are 16-byte aligned -> 16-B LDS-DMA
+
+  // ---- plan: lane c computes the I2 footprint of chunk c (bit 30 = stage through LDS, bit 29 = skip) ----
+  int plan_x = 0, plan_y = 0, plan_w = 0;  // x_lo | flags, y_lo, columns | rows << 16 of the footprint
+  {
+    const int yc0 = y_begin + lane * CH;
+    const int rows = min(CH, y_end - yc0);
+    const bool skip = (lane >= nchunks) | (frame_on & ((yc0 + rows <= a.delta) | (yc0 >= H - a.delta)));
+    bool stage = false;
+    int x_lo = 0, y_lo = 0;
+    if constexpr (kB) {
+      // the image of the chunk rectangle under an affine / projective map is the convex quadrilateral of its
+      // mapped corners (denominator checked positive), so the corner positions bound every sampling position
+      const float xl = (float)x_t0, xr = (float)min(x_t0 + kTileW - 1, W - 1);
+      const float yt = (float)yc0, yb = (float)(yc0 + rows - 1);
+      float dxs[4], dys[4];
+      displacement<kProj>(A, xl, yt, dxs[0], dys[0]);
+      displacement<kProj>(A, xr, yt, dxs[1], dys[1]);
+      displacement<kProj>(A, xl, yb, dxs[2], dys[2]);
+      displacement<kProj>(A, xr, yb, dxs[3], dys[3]);
+      const float px0 = fminf(fminf(xl + dxs[0], xr + dxs[1]), fminf(xl + dxs[2], xr + dxs[3]));
+      const float px1 = fmaxf(fmaxf(xl + dxs[0], xr + dxs[1]), fmaxf(xl + dxs[2], xr + dxs[3]));
+      const float py0 = fminf(fminf(yt + dys[0], yt + dys[1]), fminf(yb + dys[2], yb + dys[3]));
+      const float py1 = fmaxf(fmaxf(yt + dys[0], yt + dys[1]), fmaxf(yb + dys[2], yb + dys[3]));
+      bool sane = (fabsf(px0) < 1.0e6f) & (fabsf(px1) < 1.0e6f) & (fabsf(py0) < 1.0e6f) & (fabsf(py1) < 1.0e6f);
+      if constexpr (kProj) {
+        const float g0 = fmaf(A[6], xl, A[7] * yt), g1 = fmaf(A[6], xr, A[7] * yt);
+        const float g2 = fmaf(A[6], xl, A[7] * yb), g3 = fmaf(A[6], xr, A[7] * yb);
+        sane = sane & (fminf(fminf(g0, g1), fminf(g2, g3)) > -0.5f);
+      }
+      if (sane) {
+        // taps of a pixel sampled at X: columns floor(X)-1 .. floor(X)+2; one more pixel of slack for fp32
+        // rounding; x_lo is rounded down to a multiple of 4 so that 16-byte copies stay aligned
+        x_lo = max(0, (int)floorf(px0) - 2) & ~3;
+        y_lo = max(0, (int)floorf(py0) - 2);
+        const int x_hi = min(W - 1, (int)floorf(px1) + 3);
+        const int y_hi = min(H - 1, (int)floorf(py1) + 3);
+        const int bw = x_hi - x_lo + 1, bh = y_hi - y_lo + 1;
+        stage = (bw >= 1) & (bh >= 1) & (bw <= P2) & (bh <= R2);
+        plan_w = bw | (bh << 16);
+      }
+    }
+    plan_x = x_lo | (stage ? (1 << 30) : 0) | (skip ? (1 << 29) : 0);
+    plan_y = y_lo;
+  }
+
+  // ---- LDS-DMA plumbing.  Buffer descriptors give hardware range checking (rows above / below the image are
+  // simply dropped) and 32-bit offsets; the per-thread element offsets do not depend on the chunk, so a copy
+  // costs one VALU add per 16-byte element.  Element e of a buffer = float4 number e in row-major order.
+  const auto rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)I1, 0, (int)(C * plane * sizeof(float)), 0x00020000);
+  constexpr int V1 = P1 / 4, V2 = P2 / 4;                       // float4 per buffer row
+  constexpr int J1 = (R1 * V1 + kBlock - 1) / kBlock, J2 = (R2 * V2 + kBlock - 1) / kBlock;
+  constexpr unsigned kPoison = 0x80000000u;                     // offset that is always out of range
+  unsigned off1[J1], off2[J2];
+  int c42[J2];
+#pragma unroll
+  for (int j = 0; j < J1; ++j) {
+    const int e = threadIdx.x + j * kBlock, r = e / V1, c4 = e - r * V1;
+    const int xx = x_t0 - 4 + 4 * c4;
+    off1[j] = (e < R1 * V1 && xx >= 0 && xx < W) ? (unsigned)((r * W + 4 * c4 - 4) * 4) : kPoison;
+  }
+#pragma unroll
+  for (int j = 0; j < J2; ++j) {
+    const int e = threadIdx.x + j * kBlock, r = e / V2, c4 = e - r * V2;
+    off2[j] = (e < R2 * V2) ? (unsigned)((r * W + 4 * c4) * 4) : kPoison;
+    c42[j] = 4 * c4;
+  }
+
+  // issue the LDS-DMA copies of chunk k into buffer `buf` (no waits here)
+  auto issue = [&](int k, int buf) {
+    const int px = __builtin_amdgcn_readlane(plan_x, k), y_lo = __builtin_amdgcn_readlane(plan_y, k);
+    if (px & (1 << 29)) return;
+    float* b2 = lds + buf * TC::buf_floats;
+    float* b1 = b2 + C * P2 * R2;
+    const int yc0 = y_begin + k * CH;
+    if (w4) {
+      const unsigned base1 = (unsigned)(((yc0 - 1) * W + x_t0) * 4);  // may wrap below 0: then out of range
+#pragma unroll
+      for (int j = 0; j < J1; ++j) {
+        float* dst = b1 + (wave * 64 + j * kBlock) * 4;
+        const unsigned o = (off1[j] == kPoison) ? kPoison : off1[j] + base1;
+        // lanes past the end of the buffer must not take part at all: an out-of-range lane still writes its
+        // (zero) result to LDS, which would land in the neighbouring buffer
+        if ((int)threadIdx.x + j * kBlock < R1 * V1)
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (__attribute__((address_space(3))) void*)(dst + c * P1 * R1), 16,
+                                                   (int)(o + (unsigned)(c * plane * 4)), 0, 0, 0);
+      }
+      if (kB && (px & (1 << 30))) {
+        const int x_lo = px & 0xFFFFF;
+        const int bw = __builtin_amdgcn_readlane(plan_w, k);  // columns needed, rows needed
+        const int bh = bw >> 16;
+        // rows beyond the footprint fall outside this descriptor
+        const auto rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)I2, 0, (int)(((size_t)(C - 1) * plane + (size_t)(y_lo + bh) * W) * 4),
+                                                           0x00020000);
+        const unsigned base2 = (unsigned)((y_lo * W + x_lo) * 4);
+#pragma unroll
+        for (int j = 0; j < J2; ++j) {
+          float* dst = b2 + (wave * 64 + j * kBlock) * 4;
+          const unsigned o = (off2[j] == kPoison || c42[j] >= (bw & 0xFFFF)) ? kPoison : off2[j] + base2;
+          if ((int)threadIdx.x + j * kBlock < R2 * V2)
+#pragma unroll
+          for (int c = 0; c < C; ++c)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (__attribute__((address_space(3))) void*)(dst + c * P2 * R2), 16,
+                                                     (int)(o + (unsigned)(c * plane * 4)), 0, 0, 0);
+        }
+      }
+    } else {
+      for (int r = wave; r < R1; r += kWaves) {
+        const int yy = yc0 - 1 + r;
+        if (yy < 0 || yy >= H) continue;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const float* src = I1 + c * plane + (size_t)yy * W + (x_t0 - 4);
+          float* dst = b1 + c * P1 * R1 + r * P1;
+          if ((x_t0 - 4 + lane >= 0) & (x_t0 - 4 + lane < W)) glds4(src + lane, dst);
+          if ((lane < P1 - 64) & (x_t0 + 60 + lane < W)) glds4(src + 64 + lane, dst + 64);
+        }
+      }
+      if (kB && (px & (1 << 30))) {
+        const int x_lo = px & 0xFFFFF;
+        for (int r = wave; r < R2; r += kWaves) {
+          const int yy = y_lo + r;
+          if (yy >= H) break;
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            const float* src = I2 + c * plane + (size_t)yy * W + x_lo;
+            float* dst = b2 + c * P2 * R2 + r * P2;
+            if (x_lo + lane < W) glds4(src + lane, dst);
+            if ((lane < P2 - 64) & (x_lo + 64 + lane < W)) glds4(src + 64 + lane, dst + 64);
+          }
+        }
+      }
+    }
+  };
+
+  float m32[NMOM];
+  double m64[NMOM];
+#pragma unroll
+  for (int i = 0; i < NMOM; ++i) { m32[i] = 0.f; m64[i] = 0.0; }
+
+  if (NBUF == 2) issue(0, 0);
+  for (int k = 0; k < nchunks; ++k) {
+    const int buf = (NBUF == 2) ? (k & 1) : 0;
+    if (NBUF == 1) {
+      __syncthreads();  // everyone is done reading the single buffer
+      issue(k, 0);
+    }
+    __syncthreads();    // drains this wave's LDS-DMA (vmcnt) and publishes chunk k
+    if (NBUF == 2 && k + 1 < nchunks) issue(k + 1, buf ^ 1);  // flies underneath the arithmetic below
+
+    const int px = __builtin_amdgcn_readlane(plan_x, k), y_lo = __builtin_amdgcn_readlane(plan_y, k);
+    if (px & (1 << 29)) continue;
+    const bool staged = (px & (1 << 30)) != 0;
+    const int x_lo = px & 0xFFFFF;
+    const float* b2 = lds + buf * TC::buf_floats;
+    const float* b1 = b2 + C * P2 * R2;
+    const int yc0 = y_begin + k * CH;
+    const int yb0 = yc0 + wave * RW;
+    const float* i1p = b1 + (wave * RW) * P1 + lane + 4;  // row yb0-1 of this lane's column
+
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      const int y = yb0 + i;  // wave-uniform
+      const bool row_live = (y < y_end) & !(frame_on & ((y < a.delta) | (y >= H - a.delta)));
+      const bool row_inner = (y >= 1) & (y <= H - 2);  // ref :82
+      const bool live = col_ok & row_live;
+      const float yf = (float)y;
+      float mid[C], ix2[C], iy2[C];  // 2*Ix, 2*Iy (the 1/2 is applied once per tile)
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float* q = i1p + c * P1 * R1 + i * P1;
+        mid[c] = q[P1];
+        // selects (not multiplies): rows / columns outside the image were never copied and may hold anything
+        ix2[c] = (col_inner & live) ? (q[P1 + 1] - q[P1 - 1]) : 0.0f;
+        iy2[c] = (row_inner & live) ? (q[2 * P1] - q[0]) : 0.0f;
+      }
+      float di[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) di[c] = 0.f;
+      if constexpr (kB) {
+        float dxw, dyw;
+        displacement_col<kProj>(A, cx, cy, gxc, xf, yf, dxw, dyw);
+        const float flx = floorf(dxw), fly = floorf(dyw);
+        // 4x4 footprint inside the image (bicubic_interpolation.py:199, cval=nan); float compares, so a NaN or
+        // infinite position is simply "outside"
+        const bool valid = live & (flx >= vx_lo) & (flx <= vx_hi) & (fly >= (float)(1 - y)) & (fly <= (float)(H - 3 - y));
+        const int x0 = x + (int)flx, y0 = y + (int)fly;
+        float wx[4], wy[4];
+        keys_weights(dxw - flx, wx);
+        keys_weights(dyw - fly, wy);
+        float iw[C];
+        if (staged) {
+          const int aoff = valid ? __mul24(y0 - 1 - y_lo, P2) + (x0 - 1 - x_lo) : 0;
+          const float* t = b2 + aoff;
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            const float* q = t + c * P2 * R2;
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float s = wx[0] * q[r * P2];
+              s = __builtin_fmaf(wx[1], q[r * P2 + 1], s);
+              s = __builtin_fmaf(wx[2], q[r * P2 + 2], s);
+              s = __builtin_fmaf(wx[3], q[r * P2 + 3], s);
+              v = __builtin_fmaf(wy[r], s, v);
+            }
+            iw[c] = v;
+          }
+        } else {
+          const float* t = I2 + (valid ? (size_t)(y0 - 1) * W + (x0 - 1) : 0);
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            const float* q = t + c * plane;
+            float v = 0.f;
+            if (valid) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float* rp = q + (size_t)r * W;
+                float s = wx[0] * rp[0];
+                s = __builtin_fmaf(wx[1], rp[1], s);
+                s = __builtin_fmaf(wx[2], rp[2], s);
+                s = __builtin_fmaf(wx[3], rp[3], s);
+                v = __builtin_fmaf(wy[r], s, v);
+              }
+            }
+            iw[c] = v;
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const float d = fminf(fmaxf(iw[c], lo), hi) - mid[c];          // clip (skimage warp), ref :114
+          di[c] = (valid & (fabsf(d) <= 3.0e38f)) ? d : 0.0f;           // NaN / outside -> 0 (io.py:99)
+        }
+      }
+      float w = live ? 1.0f : 0.0f;  // pixels in the NaN frame contribute nothing (derivatives.py:84)
+      if constexpr (MODE == kModeRobust) {
+        float t2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) t2 = fmaf(di[c], di[c], t2);
+        w = live ? rho_prime(t2, lam2, a.robust_type) : 0.0f;  // rho'(0) where the warp is outside
+      }
+      if constexpr (kB) {
+        float gx = 0.f, gy = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) { gx = fmaf(ix2[c], di[c], gx); gy = fmaf(iy2[c], di[c], gy); }
+        if constexpr (MODE == kModeRobust) { gx *= w; gy *= w; }
+        m32[ML::ogx] += gx;
+        if constexpr (ML::mbx >= 1) m32[ML::ogx + 1] = fmaf(gx, yf, m32[ML::ogx + 1]);
+        m32[ML::ogy] += gy;
+        if constexpr (ML::mby >= 1) m32[ML::ogy + 1] = fmaf(gy, yf, m32[ML::ogy + 1]);
+        if constexpr (ML::mby >= 2) m32[ML::ogy + 2] = fmaf(gy, yf * yf, m32[ML::ogy + 2]);
+      }
+      if constexpr (kH) {
+        float sxx = 0.f, sxy = 0.f, syy = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          sxx = fmaf(ix2[c], ix2[c], sxx);
+          sxy = fmaf(ix2[c], iy2[c], sxy);
+          syy = fmaf(iy2[c], iy2[c], syy);
+        }
+        sxx *= w; sxy *= w; syy *= w;
+        float yp = 1.0f;
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+          if (b < ML::nxx) m32[ML::oxx + b] = fmaf(sxx, yp, m32[ML::oxx + b]);
+          if (b < ML::nxy) m32[ML::oxy + b] = fmaf(sxy, yp, m32[ML::oxy + b]);
+          if (b < ML::nyy) m32[ML::oyy + b] = fmaf(syy, yp, m32[ML::oyy + b]);
+          yp *= yf;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NMOM; ++i) { m64[i] += (double)m32[i]; m32[i] = 0.f; }
+  }
+
+  // ---- fold the per-column moments into the tile's partial sums (fixed order) ----
+  __syncthreads();
+  double* mom = reinterpret_cast<double*>(lds);   // [NMOM][64] moments of the whole tile, per column
+  double* con = mom + NMOM * 64;                  // [N + NT][64] per-column contribution to each output sum
+  static_assert(sizeof(float) * NBUF * TC::buf_floats >= sizeof(double) * (NMOM + N + NT) * 64, "fold scratch must fit");
+  for (int wv = 0; wv < kWaves; ++wv) {           // waves take turns: deterministic wave order
+    if (wave == wv) {
+#pragma unroll
+      for (int i = 0; i < NMOM; ++i) {
+        if (wv == 0) mom[i * 64 + lane] = m64[i];
+        else mom[i * 64 + lane] += m64[i];
+      }
+    }
+    __syncthreads();
+  }
+  {
+    // every lane applies its own x powers; the (N + NT) outputs are dealt round-robin to the 4 waves
+    double xp[5];
+    xp[0] = 1.0;
+#pragma unroll
+    for (int i = 1; i < 5; ++i) xp[i] = xp[i - 1] * (double)x;
+    auto term = [&](Mono j1, Mono j2, int base) -> double {  // j1 * j2 * moment, all indices compile-time
+      return (double)(j1.c * j2.c) * xp[j1.a + j2.a] * mom[(base + j1.b + j2.b) * 64 + lane];
+    };
+    int e = 0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {   // b_k (halved: the gradients were accumulated as 2*Ix, 2*Iy)
+      if (kB && (e & 3) == wave) {
+        constexpr Mono one{1, 0, 0};
+        const Mono jx = jac_x(TT, k), jy = jac_y(TT, k);
+        double v = 0.0;
+        if (jx.c) v += term(jx, one, ML::ogx);
+        if (jy.c) v += term(jy, one, ML::ogy);
+        con[e * 64 + lane] = 0.5 * v;
+      }
+      ++e;
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+#pragma unroll
+      for (int m = k; m < N; ++m) {  // H_km (quartered)
+        if (kH && (e & 3) == wave) {
+          const Mono jxk = jac_x(TT, k), jyk = jac_y(TT, k), jxm = jac_x(TT, m), jym = jac_y(TT, m);
+          double v = 0.0;
+          if (jxk.c && jxm.c) v += term(jxk, jxm, ML::oxx);
+          if (jxk.c && jym.c) v += term(jxk, jym, ML::oxy);
+          if (jyk.c && jxm.c) v += term(jyk, jxm, ML::oxy);
+          if (jyk.c && jym.c) v += term(jyk, jym, ML::oyy);
+          con[e * 64 + lane] = 0.25 * v;
+        }
+        ++e;
+      }
+    }
+  }
+  __syncthreads();
+  {
+    const int t = threadIdx.x;
+    const int e = t >> 2, q = t & 3;   // 4 threads per output, 16 columns each, then a fixed 2-step tree
+    double val = 0.0;
+    const bool have = (e < N) ? kB : (e < N + NT ? kH : false);
+    if (have) {
+#pragma unroll
+      for (int l = 0; l < 16; ++l) val += con[e * 64 + q * 16 + l];
+    }
+    val += __shfl_down(val, 2, 64);
+    val += __shfl_down(val, 1, 64);
+    if (q == 0 && have) {
+      double* out = a.partials + ((size_t)pair * (a.tiles_x * a.tiles_y) + tile_id) * kAccStride;
+      out[e < N ? e : kMaxN + (e - N)] = val;
+    }
+  }
+}
+
+}  // namespace ica

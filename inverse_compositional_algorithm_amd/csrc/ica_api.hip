@@ -13,6 +13,7 @@
 
 #include "../../include/ica_hip.h"
 #include "ica_kernels.hpp"
+#include "ica_accumulate2.hpp"
 #include "ica_pyramid.hpp"
 
 using namespace ica;
@@ -40,9 +41,10 @@ struct DevBuf {
 };
 
 struct DeviceBandOp {
-  DevBuf start, w;
+  DevBuf start, w, wT;
   int n_in = 0, n_out = 0, K = 0;
-  BandOp view() const { return BandOp{start.as<int>(), w.as<double>(), n_in, n_out, K}; }
+  int span_pad = 0;  // LDS row pitch (floats) of the horizontal pass: widest 64-output input span, made odd
+  BandOp view() const { return BandOp{start.as<int>(), w.as<double>(), wT.as<double>(), n_in, n_out, K}; }
 };
 
 struct LevelGeom {
@@ -70,6 +72,7 @@ struct ica_ctx {
     for (auto& kv : ops) {
       kv.second->start.release();
       kv.second->w.release();
+      kv.second->wT.release();
       delete kv.second;
     }
     for (auto e : ev_pool) (void)hipEventDestroy(e);
@@ -140,18 +143,27 @@ int get_op(ica_ctx* ctx, int n_in, int n_out, DeviceBandOp** out) {
     return ICA_OK;
   }
   HostBandOp h = build_rescale_op(n_in, n_out);
+  std::vector<double> wT((size_t)h.K * n_out);
+  for (int o = 0; o < n_out; ++o)
+    for (int k = 0; k < h.K; ++k) wT[(size_t)k * n_out + o] = h.w[(size_t)o * h.K + k];
   auto* d = new DeviceBandOp();
   d->n_in = n_in;
   d->n_out = n_out;
   d->K = h.K;
+  int span = 1;
+  for (int o = 0; o < n_out; o += 64) span = std::max(span, h.start[std::min(o + 63, n_out - 1)] + h.K - h.start[o]);
+  d->span_pad = span | 1;
   hipError_t e = d->start.ensure(h.start.size() * sizeof(int));
   if (e == hipSuccess) e = d->w.ensure(h.w.size() * sizeof(double));
+  if (e == hipSuccess) e = d->wT.ensure(wT.size() * sizeof(double));
   if (e == hipSuccess) e = hipMemcpy(d->start.ptr, h.start.data(), h.start.size() * sizeof(int), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(d->w.ptr, h.w.data(), h.w.size() * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d->wT.ptr, wT.data(), wT.size() * sizeof(double), hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     ctx->last_error = std::string("pyramid operator upload: ") + hipGetErrorString(e);
     d->start.release();
     d->w.release();
+    d->wT.release();
     delete d;
     return e == hipErrorOutOfMemory ? ICA_ENOMEM : ICA_EHIP;
   }
@@ -177,43 +189,45 @@ int launch_pyramid_down(ica_ctx* ctx, int batch, int C, int H, int W, int h, int
   ICA_TRY(get_op(ctx, W, w, &ox));
   ICA_TRY(get_op(ctx, H, h, &oy));
   const int planes = batch * C;
-  ICA_HIP(ctx, ctx->tmp_resample.ensure((size_t)planes * H * w * sizeof(float)));
+  const size_t lds = (size_t)kRowsH * ox->span_pad * sizeof(float);
+  if (lds > 64 * 1024) {
+    ctx->last_error = "pyramid step: downsampling factor too large for the LDS-tiled horizontal pass";
+    return ICA_EINVAL_ARG;
+  }
+  ICA_HIP(ctx, ctx->tmp_resample.ensure((size_t)planes * h * W * sizeof(float)));
   ICA_HIP(ctx, ctx->mm_in.ensure((size_t)batch * 2 * sizeof(float)));
   ICA_TRY(launch_minmax(ctx, batch, (size_t)C * H * W, in, ctx->mm_in.as<float>()));
-  // planes go on grid.z (<= 65535): split if needed
-  for (int p0 = 0; p0 < planes; p0 += 32768) {
-    const int np = std::min(32768, planes - p0);
-    hipLaunchKernelGGL(ica_resample_x_kernel, dim3((w + 63) / 64, (H + kWaves - 1) / kWaves, np), dim3(kBlock), 0,
-                       ctx->stream, in + (size_t)p0 * H * W, ctx->tmp_resample.as<float>() + (size_t)p0 * H * w, np, H,
-                       ox->view());
-  }
-  if (C == 1 || (32768 % C) == 0 || planes <= 32768) {
-    const int step = (planes <= 32768) ? planes : (32768 / C) * C;
-    for (int p0 = 0; p0 < planes; p0 += step) {
-      const int np = std::min(step, planes - p0);
-      hipLaunchKernelGGL(ica_resample_y_kernel, dim3((w + 63) / 64, (h + kWaves - 1) / kWaves, np), dim3(kBlock), 0,
-                         ctx->stream, ctx->tmp_resample.as<float>() + (size_t)p0 * H * w, out + (size_t)p0 * h * w, np, C,
-                         w, oy->view(), ctx->mm_in.as<float>() + (size_t)(p0 / C) * 2);
-    }
-  } else {
-    const int step = (32768 / C) * C;
-    for (int p0 = 0; p0 < planes; p0 += step) {
-      const int np = std::min(step, planes - p0);
-      hipLaunchKernelGGL(ica_resample_y_kernel, dim3((w + 63) / 64, (h + kWaves - 1) / kWaves, np), dim3(kBlock), 0,
-                         ctx->stream, ctx->tmp_resample.as<float>() + (size_t)p0 * H * w, out + (size_t)p0 * h * w, np, C,
-                         w, oy->view(), ctx->mm_in.as<float>() + (size_t)(p0 / C) * 2);
-    }
+  float* tmp = ctx->tmp_resample.as<float>();
+  // planes ride on grid.z (<= 65535): chunk on whole pairs so the clip range index stays aligned
+  const int step = std::max(C, (32768 / C) * C);
+  for (int p0 = 0; p0 < planes; p0 += step) {
+    const int np = std::min(step, planes - p0);
+    hipLaunchKernelGGL(ica_resample_v_kernel, dim3((W + 63) / 64, (h + kWaves * kOutsV - 1) / (kWaves * kOutsV), np),
+                       dim3(kBlock), 0, ctx->stream, in + (size_t)p0 * H * W, tmp + (size_t)p0 * h * W, np, W, oy->view());
+    hipLaunchKernelGGL(ica_resample_h_kernel, dim3((w + 63) / 64, (h + kRowsH - 1) / kRowsH, np), dim3(kBlock), lds,
+                       ctx->stream, tmp + (size_t)p0 * h * W, out + (size_t)p0 * h * w, np, C, h, ox->view(),
+                       ctx->mm_in.as<float>() + (size_t)(p0 / C) * 2, ox->span_pad);
   }
   ICA_HIP(ctx, hipGetLastError());
   return ICA_OK;
 }
 
+// ICA_ACCUM=1 selects the simple direct-gather kernel (kept as an in-library cross-check of the LDS-staged one)
+int g_accum_variant = 2;
+
 template <int TT, int MODE>
 void launch_accumulate_c(int C, dim3 grid, hipStream_t st, const LevelArgs& a) {
-  if (C == 1)
-    hipLaunchKernelGGL((ica_accumulate_kernel<TT, MODE, 1>), grid, dim3(kBlock), 0, st, a);
-  else
-    hipLaunchKernelGGL((ica_accumulate_kernel<TT, MODE, 3>), grid, dim3(kBlock), 0, st, a);
+  if (g_accum_variant == 1) {
+    if (C == 1)
+      hipLaunchKernelGGL((ica_accumulate_kernel<TT, MODE, 1>), grid, dim3(kBlock), 0, st, a);
+    else
+      hipLaunchKernelGGL((ica_accumulate_kernel<TT, MODE, 3>), grid, dim3(kBlock), 0, st, a);
+  } else {
+    if (C == 1)
+      hipLaunchKernelGGL((ica_accumulate2_kernel<TT, MODE, 1>), grid, dim3(kBlock), 0, st, a);
+    else
+      hipLaunchKernelGGL((ica_accumulate2_kernel<TT, MODE, 3>), grid, dim3(kBlock), 0, st, a);
+  }
 }
 
 template <int MODE>
@@ -275,7 +289,7 @@ int ensure_state(ica_ctx* ctx, const ica_problem* pr, const LevelGeom* g) {
     ICA_TRY(get_op(ctx, g[s - 1].H, g[s].H, &tmp));
   }
   if (pr->nscales > 1)
-    ICA_HIP(ctx, ctx->tmp_resample.ensure(B * pr->channels * g[0].H * g[1].W * sizeof(float)));
+    ICA_HIP(ctx, ctx->tmp_resample.ensure(B * pr->channels * g[1].H * g[0].W * sizeof(float)));
   if (!ctx->pinned_count) ICA_HIP(ctx, hipHostMalloc((void**)&ctx->pinned_count, 4 * sizeof(int), hipHostMallocDefault));
   return ICA_OK;
 }
@@ -319,6 +333,7 @@ int ica_create(int device, ica_ctx** out) {
   auto* c = new ica_ctx();
   c->device = device;
   if (const char* e = getenv("ICA_POLL_EVERY")) c->poll_every = std::max(1, atoi(e));
+  if (const char* e = getenv("ICA_ACCUM")) g_accum_variant = (atoi(e) == 1) ? 1 : 2;
   *out = c;
   return ICA_OK;
 }

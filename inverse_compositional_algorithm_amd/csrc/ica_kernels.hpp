@@ -536,46 +536,88 @@ __global__ void ica_zoom_params_kernel(int batch, int tt, int w, int h, int ww, 
 struct BandOp {
   const int* start;    // [n_out] first input index of the band
   const double* w;     // [n_out][K]
+  const double* wT;    // [K][n_out] (same weights, transposed for lane-contiguous reads)
   int n_in, n_out, K;
 };
 
-// out[b][c][y][o] = sum_k w[o][k] * in[b][c][y][start[o]+k]
-__global__ __launch_bounds__(kBlock) void ica_resample_x_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                                int planes, int H, BandOp op) {
-  const int o = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * kWaves + (threadIdx.x >> 6);
+constexpr int kOutsV = 8;    // consecutive output rows per wave in the vertical pass
+constexpr int kRowsH = 32;   // rows per workgroup in the horizontal pass (8 per wave)
+
+// Vertical pass: in [planes][n_in][W] -> out [planes][n_out][W].
+// lane = column (coalesced 256-B row segments); each wave produces 8 consecutive output rows, so every
+// input value is loaded once and used for up to 8 outputs.  Band starts / weights are wave-uniform
+// (scalar loads), accumulation in fp64.
+__global__ __launch_bounds__(kBlock) void ica_resample_v_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                int planes, int W, BandOp op) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int o0 = (blockIdx.y * kWaves + wave) * kOutsV;
   const int pl = blockIdx.z;
-  if (o >= op.n_out || y >= H || pl >= planes) return;
-  const float* row = in + ((size_t)pl * H + y) * op.n_in;
-  const int s = op.start[o];
-  const double* w = op.w + (size_t)o * op.K;
-  double acc = 0.0;
-  for (int k = 0; k < op.K; ++k) {
-    const int j = s + k;
-    if (j >= 0 && j < op.n_in) acc += w[k] * (double)row[j];
+  if (o0 >= op.n_out) return;
+  const int no = min(kOutsV, op.n_out - o0);
+  int st[kOutsV];
+#pragma unroll
+  for (int i = 0; i < kOutsV; ++i) st[i] = op.start[min(o0 + i, op.n_out - 1)];
+  const int j0 = st[0];
+  const int j1 = min(op.n_in, st[no - 1] + op.K);
+  double acc[kOutsV];
+#pragma unroll
+  for (int i = 0; i < kOutsV; ++i) acc[i] = 0.0;
+  const bool xin = x < W;
+  const float* col = in + (size_t)pl * op.n_in * W + (xin ? x : 0);
+  for (int j = j0; j < j1; ++j) {
+    const double v = xin ? (double)col[(size_t)j * W] : 0.0;
+#pragma unroll
+    for (int i = 0; i < kOutsV; ++i) {
+      const int k = j - st[i];
+      if (i < no && k >= 0 && k < op.K) acc[i] = fma(op.w[(size_t)(o0 + i) * op.K + k], v, acc[i]);
+    }
   }
-  out[((size_t)pl * H + y) * op.n_out + o] = (float)acc;
+  if (xin) {
+#pragma unroll
+    for (int i = 0; i < kOutsV; ++i)
+      if (i < no) out[((size_t)pl * op.n_out + o0 + i) * W + x] = (float)acc[i];
+  }
 }
 
-// out[b][c][o][x] = clip(sum_k w[o][k] * in[b][c][start[o]+k][x], minmax of the pair)
-__global__ __launch_bounds__(kBlock) void ica_resample_y_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                                int planes, int channels, int W, BandOp op,
-                                                                const float* __restrict__ minmax) {
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int o = blockIdx.y * kWaves + (threadIdx.x >> 6);
-  const int pl = blockIdx.z;
-  if (x >= W || o >= op.n_out || pl >= planes) return;
-  const float* col = in + (size_t)pl * op.n_in * W + x;
-  const int s = op.start[o];
-  const double* w = op.w + (size_t)o * op.K;
-  double acc = 0.0;
+// Horizontal pass + clip: in [planes][H][n_in] -> out [planes][H][n_out].
+// A workgroup stages 32 rows x (input span of 64 outputs) in LDS with coalesced loads; lane = output column,
+// each thread accumulates 8 rows so one (coalesced, transposed) weight load feeds 8 fp64 FMAs.
+__global__ __launch_bounds__(kBlock) void ica_resample_h_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                int planes, int channels, int H, BandOp op,
+                                                                const float* __restrict__ minmax, int span_pad) {
+  extern __shared__ float tile[];  // [kRowsH][span_pad]
+  const int o_base = blockIdx.x * 64, r_base = blockIdx.y * kRowsH, pl = blockIdx.z;
+  const int o_last = min(o_base + 63, op.n_out - 1);
+  const int c0 = op.start[o_base];
+  const int span = op.start[o_last] + op.K - c0;  // <= span_pad
+  const float* src = in + (size_t)pl * H * op.n_in;
+  for (int idx = threadIdx.x; idx < kRowsH * span; idx += kBlock) {
+    const int r = idx / span, c = idx - r * span;
+    const int y = r_base + r, xg = c0 + c;
+    tile[r * span_pad + c] = (y < H && xg < op.n_in) ? src[(size_t)y * op.n_in + xg] : 0.0f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int o = o_base + lane;
+  if (o >= op.n_out) return;
+  const int s = op.start[o] - c0;
+  double acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.0;
+  const float* t0 = tile + (rg * 8) * span_pad + s;
   for (int k = 0; k < op.K; ++k) {
-    const int j = s + k;
-    if (j >= 0 && j < op.n_in) acc += w[k] * (double)col[(size_t)j * W];
+    const double wk = op.wT[(size_t)k * op.n_out + o];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = fma(wk, (double)t0[i * span_pad + k], acc[i]);
   }
   const int pair = pl / channels;
-  const float v = fminf(fmaxf((float)acc, minmax[pair * 2]), minmax[pair * 2 + 1]);
-  out[((size_t)pl * op.n_out + o) * W + x] = v;
+  const float lo = minmax[pair * 2], hi = minmax[pair * 2 + 1];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int y = r_base + rg * 8 + i;
+    if (y < H) out[((size_t)pl * H + y) * op.n_out + o] = fminf(fmaxf((float)acc[i], lo), hi);
+  }
 }
 
 }  // namespace ica

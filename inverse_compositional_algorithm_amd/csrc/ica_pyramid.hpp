@@ -11,7 +11,7 @@
 // Steps 1-2 are linear and act on one axis at a time, so the whole thing is one (n_out x n_in) matrix per
 // axis.  It is built here in float64 by pushing unit impulses through the same three stages, then stored
 // as a band (the prefilter's impulse response decays like 0.268^k).  The device applies the two banded
-// operators separably (ica_resample_{x,y}_kernel).
+// operators separably (ica_resample_{v,h}_kernel).
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -104,7 +104,8 @@ inline HostBandOp build_rescale_op(int n_in, int n_out) {
     }
   }
   // band extraction
-  const double eps = 1e-13;
+  // weights below 1e-10 cannot move a float32 output (values <= ~1e3, 24-bit mantissa)
+  const double eps = 1e-10;
   op.start.resize(n_out);
   std::vector<int> last(n_out);
   int K = 1;
