@@ -10,7 +10,7 @@ ICA_TRACE_STRIDE = 10
 ICA_FLAG_EXACT_UPDATE = 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libica_hip.so")
+LIB_PATH = os.environ.get("ICA_LIB", os.path.join(_HERE, "libica_hip.so"))  # ICA_LIB: experiment builds only
 
 
 class IcaError(RuntimeError):

@@ -27,6 +27,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB, SRC]
+    cmd += os.environ.get("ICA_EXTRA_FLAGS", "").split()  # e.g. -DICA_ABLATE=1 for timing-only experiments
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=HERE)

@@ -20,6 +20,18 @@
 //      once per tile, in fp64, when the 64 lanes' moments are folded into the <= 44 sums.
 //   fp32 per pixel, promoted to fp64 after every wave band; fixed summation order throughout (deterministic).
 #pragma once
+#include <type_traits>
+
+#ifndef ICA_ROW_UNROLL
+#define ICA_ROW_UNROLL 1
+#endif
+#ifndef ICA_NBUF
+#define ICA_NBUF 2
+#endif
+#ifndef ICA_R2
+#define ICA_R2 25
+#endif
+
 #include "ica_kernels.hpp"
 
 namespace ica {
@@ -68,9 +80,11 @@ template <int TT> struct MomLayout {
 template <int C> struct TileCfg {
   static constexpr int ch = 16;                        // image rows per chunk: 4 waves x 4 rows
   static constexpr int rw = ch / kWaves;
-  static constexpr int p2 = 96, r2 = 32;               // I2 footprint buffer: pitch (floats) x rows
+  static constexpr int p2 = 80, r2 = ICA_R2;               // I2 footprint buffer: pitch (floats) x rows
   static constexpr int p1 = 72, r1 = ch + 2;           // I1 buffer: columns x_t0-4 .. x_t0+67, rows yc0-1 .. yc0+ch
-  static constexpr int nbuf = (C == 1) ? 2 : 1;        // double buffering where LDS allows 4 workgroups per CU
+  // C == 1: a ring of 3 buffers (40.5 KB -> 4 workgroups per CU): chunk k is computed while k+1 and k+2 are in
+  // flight.  C == 3: one buffer (40.5 KB), copy and arithmetic of one workgroup alternate, 3 workgroups overlap.
+  static constexpr int nbuf = (C == 1) ? ICA_NBUF : 1;
   static constexpr int buf_floats = C * (p2 * r2 + p1 * r1);
 };
 
@@ -112,8 +126,11 @@ __global__ __launch_bounds__(kBlock) void ica_accumulate2_kernel(LevelArgs a) {
   constexpr int CH = TC::ch, RW = TC::rw, P2 = TC::p2, R2 = TC::r2, P1 = TC::p1, R1 = TC::r1, NBUF = TC::nbuf;
   constexpr int NMOM = ML::nmom;
 
-  __shared__ __attribute__((aligned(16))) float lds[NBUF * TC::buf_floats];
-  static_assert(sizeof(float) * NBUF * TC::buf_floats >= sizeof(double) * NMOM * 64, "moment scratch must fit");
+  // the ring buffers; the end-of-tile fold reuses the same LDS (and may need a little more for robust homography)
+  constexpr int kFoldFloats = 2 * (NMOM + N + NT) * 64;
+  constexpr int kLdsFloats = NBUF * TC::buf_floats > kFoldFloats ? NBUF * TC::buf_floats : kFoldFloats;
+  __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
+  
 
   int pair = blockIdx.y;
   if (a.act_list) {
@@ -154,7 +171,7 @@ __global__ __launch_bounds__(kBlock) void ica_accumulate2_kernel(LevelArgs a) {
   const int nchunks = (y_end - y_begin + CH - 1) / CH;  // <= 64: one lane plans one chunk (tile_h <= 1024)
   const bool frame_on = a.nanif && a.delta > 0;
   const bool col_ok = (x < W) & !(frame_on & ((x < a.delta) | (x >= W - a.delta)));
-  const bool col_inner = (x >= 1) & (x <= W - 2);       // ref :81: the 1-px border keeps a zero x-derivative
+  const float cmx = ((x >= 1) & (x <= W - 2)) ? 1.0f : 0.0f;  // ref :81: the 1-px border keeps a zero x-derivative
   const float cx = fmaf(A[0], xf, A[2]), cy = fmaf(A[3], xf, A[5]), gxc = A[6] * xf;
   const float vx_lo = (float)(1 - x), vx_hi = (float)(W - 3 - x);
   const bool w4 = (W & 3) == 0;                         // rows are 16-byte aligned -> 16-B LDS-DMA
@@ -204,68 +221,86 @@ __global__ __launch_bounds__(kBlock) void ica_accumulate2_kernel(LevelArgs a) {
   }
 
   // ---- LDS-DMA plumbing.  Buffer descriptors give hardware range checking (rows above / below the image are
-  // simply dropped) and 32-bit offsets; the per-thread element offsets do not depend on the chunk, so a copy
-  // costs one VALU add per 16-byte element.  Element e of a buffer = float4 number e in row-major order.
+  // simply dropped, the LDS slot gets 0) and 32-bit offsets; the per-thread element offsets do not depend on the
+  // chunk, so a copy costs about one VALU add per 16-byte element.  Element e of a buffer = float4 number e in
+  // row-major order.  Each buffer is covered by JF full wave-instructions per wave plus one tail instruction whose
+  // elements are dealt evenly to the 4 waves, so EVERY wave issues exactly the same number of copies per chunk --
+  // that makes the counted s_waitcnt vmcnt(kCopiesPerChunk) below exact.
   const auto rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)I1, 0, (int)(C * plane * sizeof(float)), 0x00020000);
   constexpr int V1 = P1 / 4, V2 = P2 / 4;                       // float4 per buffer row
-  constexpr int J1 = (R1 * V1 + kBlock - 1) / kBlock, J2 = (R2 * V2 + kBlock - 1) / kBlock;
+  constexpr int E1 = R1 * V1, E2 = R2 * V2;
+  constexpr int JF1 = E1 / kBlock, JF2 = E2 / kBlock;           // full instructions
+  constexpr int T1 = (E1 - JF1 * kBlock) / kWaves, T2 = (E2 - JF2 * kBlock) / kWaves;  // tail elements per wave
+  static_assert((E1 - JF1 * kBlock) % kWaves == 0 && (E2 - JF2 * kBlock) % kWaves == 0, "tail must split evenly");
+  constexpr int J1 = JF1 + (T1 > 0), J2 = JF2 + (T2 > 0);
+  constexpr int kCopiesPerChunk = C * (J1 + (kB ? J2 : 0));     // VMEM instructions per wave per chunk
   constexpr unsigned kPoison = 0x80000000u;                     // offset that is always out of range
+  auto elem1 = [&](int j) { return j < JF1 ? (int)threadIdx.x + j * kBlock : JF1 * kBlock + wave * T1 + lane; };
+  auto elem2 = [&](int j) { return j < JF2 ? (int)threadIdx.x + j * kBlock : JF2 * kBlock + wave * T2 + lane; };
   unsigned off1[J1], off2[J2];
   int c42[J2];
 #pragma unroll
   for (int j = 0; j < J1; ++j) {
-    const int e = threadIdx.x + j * kBlock, r = e / V1, c4 = e - r * V1;
+    const int e = elem1(j), r = e / V1, c4 = e - r * V1;
     const int xx = x_t0 - 4 + 4 * c4;
-    off1[j] = (e < R1 * V1 && xx >= 0 && xx < W) ? (unsigned)((r * W + 4 * c4 - 4) * 4) : kPoison;
+    off1[j] = (xx >= 0 && xx < W) ? (unsigned)((r * W + 4 * c4 - 4) * 4) : kPoison;
   }
 #pragma unroll
   for (int j = 0; j < J2; ++j) {
-    const int e = threadIdx.x + j * kBlock, r = e / V2, c4 = e - r * V2;
-    off2[j] = (e < R2 * V2) ? (unsigned)((r * W + 4 * c4) * 4) : kPoison;
+    const int e = elem2(j), r = e / V2, c4 = e - r * V2;
+    off2[j] = (unsigned)((r * W + 4 * c4) * 4);
     c42[j] = 4 * c4;
   }
 
   // issue the LDS-DMA copies of chunk k into buffer `buf` (no waits here)
   auto issue = [&](int k, int buf) {
+#if defined(ICA_ABLATE) && ICA_ABLATE == 2
+    return;  // timing-only build: no LDS-DMA
+#endif
     const int px = __builtin_amdgcn_readlane(plan_x, k), y_lo = __builtin_amdgcn_readlane(plan_y, k);
-    if (px & (1 << 29)) return;
     float* b2 = lds + buf * TC::buf_floats;
     float* b1 = b2 + C * P2 * R2;
     const int yc0 = y_begin + k * CH;
     if (w4) {
+      // a skipped (all-frame) chunk still issues its copies, with every lane out of range, to keep the count
+      const bool skip = (px & (1 << 29)) != 0;
       const unsigned base1 = (unsigned)(((yc0 - 1) * W + x_t0) * 4);  // may wrap below 0: then out of range
 #pragma unroll
       for (int j = 0; j < J1; ++j) {
-        float* dst = b1 + (wave * 64 + j * kBlock) * 4;
-        const unsigned o = (off1[j] == kPoison) ? kPoison : off1[j] + base1;
-        // lanes past the end of the buffer must not take part at all: an out-of-range lane still writes its
-        // (zero) result to LDS, which would land in the neighbouring buffer
-        if ((int)threadIdx.x + j * kBlock < R1 * V1)
-#pragma unroll
-        for (int c = 0; c < C; ++c)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (__attribute__((address_space(3))) void*)(dst + c * P1 * R1), 16,
-                                                   (int)(o + (unsigned)(c * plane * 4)), 0, 0, 0);
-      }
-      if (kB && (px & (1 << 30))) {
-        const int x_lo = px & 0xFFFFF;
-        const int bw = __builtin_amdgcn_readlane(plan_w, k);  // columns needed, rows needed
-        const int bh = bw >> 16;
-        // rows beyond the footprint fall outside this descriptor
-        const auto rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)I2, 0, (int)(((size_t)(C - 1) * plane + (size_t)(y_lo + bh) * W) * 4),
-                                                           0x00020000);
-        const unsigned base2 = (unsigned)((y_lo * W + x_lo) * 4);
-#pragma unroll
-        for (int j = 0; j < J2; ++j) {
-          float* dst = b2 + (wave * 64 + j * kBlock) * 4;
-          const unsigned o = (off2[j] == kPoison || c42[j] >= (bw & 0xFFFF)) ? kPoison : off2[j] + base2;
-          if ((int)threadIdx.x + j * kBlock < R2 * V2)
+        float* dst = b1 + (j < JF1 ? wave * 64 + j * kBlock : JF1 * kBlock + wave * T1) * 4;
+        const unsigned o = (skip || off1[j] == kPoison) ? kPoison : off1[j] + base1;
+        // tail lanes past the wave's share must not take part at all: an out-of-range lane still writes its
+        // (zero) result to LDS, which would land in another wave's slots
+        if (j < JF1 || lane < T1) {
 #pragma unroll
           for (int c = 0; c < C; ++c)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (__attribute__((address_space(3))) void*)(dst + c * P2 * R2), 16,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (__attribute__((address_space(3))) void*)(dst + c * P1 * R1), 16,
                                                      (int)(o + (unsigned)(c * plane * 4)), 0, 0, 0);
         }
       }
+      if constexpr (kB) {
+        const bool stage = !skip && (px & (1 << 30));
+        const int x_lo = px & 0xFFFFF;
+        const int bw = __builtin_amdgcn_readlane(plan_w, k);  // columns | rows << 16 of the footprint
+        const int bh = stage ? (bw >> 16) : 0;
+        // rows beyond the footprint fall outside this descriptor (a chunk that is not staged gets 0 rows)
+        const auto rs2 = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)I2, 0, bh ? (int)(((size_t)(C - 1) * plane + (size_t)(y_lo + bh) * W) * 4) : 0, 0x00020000);
+        const unsigned base2 = (unsigned)((y_lo * W + x_lo) * 4);
+#pragma unroll
+        for (int j = 0; j < J2; ++j) {
+          float* dst = b2 + (j < JF2 ? wave * 64 + j * kBlock : JF2 * kBlock + wave * T2) * 4;
+          const unsigned o = (c42[j] >= (bw & 0xFFFF)) ? kPoison : off2[j] + base2;
+          if (j < JF2 || lane < T2) {
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (__attribute__((address_space(3))) void*)(dst + c * P2 * R2), 16,
+                                                       (int)(o + (unsigned)(c * plane * 4)), 0, 0, 0);
+          }
+        }
+      }
     } else {
+      if (px & (1 << 29)) return;
       for (int r = wave; r < R1; r += kWaves) {
         const int yy = yc0 - 1 + r;
         if (yy < 0 || yy >= H) continue;
@@ -294,20 +329,35 @@ __global__ __launch_bounds__(kBlock) void ica_accumulate2_kernel(LevelArgs a) {
     }
   };
 
-  float m32[NMOM];
-  double m64[NMOM];
-#pragma unroll
-  for (int i = 0; i < NMOM; ++i) { m32[i] = 0.f; m64[i] = 0.0; }
+  if (!w4) {  // the dword copy path skips out-of-image lanes instead of zero-filling them: start from finite LDS
+    for (int i = threadIdx.x; i < kLdsFloats; i += kBlock) lds[i] = 0.f;
+    __syncthreads();
+  }
 
-  if (NBUF == 2) issue(0, 0);
+  float m32[NMOM];
+#pragma unroll
+  for (int i = 0; i < NMOM; ++i) m32[i] = 0.f;
+
+  // Ring protocol (NBUF == 3): chunks k+1 and k+2 are in flight while chunk k is computed.  A wave's copies retire
+  // in order, so "all but my newest kCopiesPerChunk copies have landed" == "my part of chunk k has landed"; the
+  // barrier then makes every wave's part visible, and also means everyone has finished reading chunk k-1, whose
+  // buffer is the one chunk k+2 is about to overwrite.
+  if (NBUF >= 2) {
+    issue(0, 0);
+    if (NBUF == 3 && nchunks > 1) issue(1, 1);
+  }
   for (int k = 0; k < nchunks; ++k) {
-    const int buf = (NBUF == 2) ? (k & 1) : 0;
+    const int buf = (NBUF >= 2) ? (k % NBUF) : 0;
     if (NBUF == 1) {
       __syncthreads();  // everyone is done reading the single buffer
       issue(k, 0);
+      __syncthreads();  // drains this wave's LDS-DMA (vmcnt(0)) and publishes chunk k
+    } else {
+      if (NBUF == 3 && w4 && k + 1 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kCopiesPerChunk) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (k + NBUF - 1 < nchunks) issue(k + NBUF - 1, (k + NBUF - 1) % NBUF);
     }
-    __syncthreads();    // drains this wave's LDS-DMA (vmcnt) and publishes chunk k
-    if (NBUF == 2 && k + 1 < nchunks) issue(k + 1, buf ^ 1);  // flies underneath the arithmetic below
 
     const int px = __builtin_amdgcn_readlane(plan_x, k), y_lo = __builtin_amdgcn_readlane(plan_y, k);
     if (px & (1 << 29)) continue;
@@ -319,21 +369,25 @@ __global__ __launch_bounds__(kBlock) void ica_accumulate2_kernel(LevelArgs a) {
     const int yb0 = yc0 + wave * RW;
     const float* i1p = b1 + (wave * RW) * P1 + lane + 4;  // row yb0-1 of this lane's column
 
-#pragma unroll
+    // the band of RW rows, compiled once for LDS taps and once for the direct-gather fallback
+    auto band = [&](auto staged_c) {
+    constexpr bool STAGED = decltype(staged_c)::value;
+#pragma unroll ICA_ROW_UNROLL
     for (int i = 0; i < RW; ++i) {
       const int y = yb0 + i;  // wave-uniform
       const bool row_live = (y < y_end) & !(frame_on & ((y < a.delta) | (y >= H - a.delta)));
-      const bool row_inner = (y >= 1) & (y <= H - 2);  // ref :82
+      const float rmy = ((y >= 1) & (y <= H - 2)) ? 1.0f : 0.0f;  // ref :82: zero y-derivative on the border rows
       const bool live = col_ok & row_live;
       const float yf = (float)y;
       float mid[C], ix2[C], iy2[C];  // 2*Ix, 2*Iy (the 1/2 is applied once per tile)
 #pragma unroll
       for (int c = 0; c < C; ++c) {
         const float* q = i1p + c * P1 * R1 + i * P1;
+        // unconditional LDS reads (the buffer only ever holds image values or the zeros the DMA writes for
+        // out-of-image elements, so masked-out lanes see finite values) and multiplicative 0/1 masks
         mid[c] = q[P1];
-        // selects (not multiplies): rows / columns outside the image were never copied and may hold anything
-        ix2[c] = (col_inner & live) ? (q[P1 + 1] - q[P1 - 1]) : 0.0f;
-        iy2[c] = (row_inner & live) ? (q[2 * P1] - q[0]) : 0.0f;
+        ix2[c] = (q[P1 + 1] - q[P1 - 1]) * cmx;
+        iy2[c] = (q[2 * P1] - q[0]) * rmy;
       }
       float di[C];
 #pragma unroll
@@ -350,7 +404,7 @@ __global__ __launch_bounds__(kBlock) void ica_accumulate2_kernel(LevelArgs a) {
         keys_weights(dxw - flx, wx);
         keys_weights(dyw - fly, wy);
         float iw[C];
-        if (staged) {
+        if constexpr (STAGED) {
           const int aoff = valid ? __mul24(y0 - 1 - y_lo, P2) + (x0 - 1 - x_lo) : 0;
           const float* t = b2 + aoff;
 #pragma unroll
@@ -430,15 +484,25 @@ __global__ __launch_bounds__(kBlock) void ica_accumulate2_kernel(LevelArgs a) {
         }
       }
     }
-#pragma unroll
-    for (int i = 0; i < NMOM; ++i) { m64[i] += (double)m32[i]; m32[i] = 0.f; }
+    };
+#if defined(ICA_ABLATE) && ICA_ABLATE == 1
+    if (a.delta < 0)  // timing-only build: staging and barriers only
+#endif
+    {
+      if (staged) band(std::true_type{});
+      else band(std::false_type{});
+    }
   }
+  // The y-moments of one lane's column over the whole tile (<= 64 rows per lane) stay in fp32 registers; they are
+  // promoted to fp64 here, before x powers up to x^4 are applied and 64 lanes x 4 waves x tiles are summed.
+  double m64[NMOM];
+#pragma unroll
+  for (int i = 0; i < NMOM; ++i) m64[i] = (double)m32[i];
 
   // ---- fold the per-column moments into the tile's partial sums (fixed order) ----
   __syncthreads();
   double* mom = reinterpret_cast<double*>(lds);   // [NMOM][64] moments of the whole tile, per column
   double* con = mom + NMOM * 64;                  // [N + NT][64] per-column contribution to each output sum
-  static_assert(sizeof(float) * NBUF * TC::buf_floats >= sizeof(double) * (NMOM + N + NT) * 64, "fold scratch must fit");
   for (int wv = 0; wv < kWaves; ++wv) {           // waves take turns: deterministic wave order
     if (wave == wv) {
 #pragma unroll

@@ -44,6 +44,7 @@ struct DeviceBandOp {
   DevBuf start, w, wT;
   int n_in = 0, n_out = 0, K = 0;
   int span_pad = 0;  // LDS row pitch (floats) of the horizontal pass: widest 64-output input span, made odd
+  int vspan = 0;     // widest input span of 8 consecutive outputs (vertical pass window)
   BandOp view() const { return BandOp{start.as<int>(), w.as<double>(), wT.as<double>(), n_in, n_out, K}; }
 };
 
@@ -153,6 +154,8 @@ int get_op(ica_ctx* ctx, int n_in, int n_out, DeviceBandOp** out) {
   int span = 1;
   for (int o = 0; o < n_out; o += 64) span = std::max(span, h.start[std::min(o + 63, n_out - 1)] + h.K - h.start[o]);
   d->span_pad = span | 1;
+  for (int o = 0; o < n_out; o += kOutsV)
+    d->vspan = std::max(d->vspan, std::min(n_in, h.start[std::min(o + kOutsV - 1, n_out - 1)] + h.K) - h.start[o]);
   hipError_t e = d->start.ensure(h.start.size() * sizeof(int));
   if (e == hipSuccess) e = d->w.ensure(h.w.size() * sizeof(double));
   if (e == hipSuccess) e = d->wT.ensure(wT.size() * sizeof(double));
@@ -190,7 +193,7 @@ int launch_pyramid_down(ica_ctx* ctx, int batch, int C, int H, int W, int h, int
   ICA_TRY(get_op(ctx, H, h, &oy));
   const int planes = batch * C;
   const size_t lds = (size_t)kRowsH * ox->span_pad * sizeof(float);
-  if (lds > 64 * 1024) {
+  if (lds > 64 * 1024 || oy->vspan > kVWin) {
     ctx->last_error = "pyramid step: downsampling factor too large for the LDS-tiled horizontal pass";
     return ICA_EINVAL_ARG;
   }

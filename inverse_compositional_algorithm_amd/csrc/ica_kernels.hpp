@@ -545,33 +545,43 @@ constexpr int kRowsH = 32;   // rows per workgroup in the horizontal pass (8 per
 
 // Vertical pass: in [planes][n_in][W] -> out [planes][n_out][W].
 // lane = column (coalesced 256-B row segments); each wave produces 8 consecutive output rows, so every
-// input value is loaded once and used for up to 8 outputs.  Band starts / weights are wave-uniform
-// (scalar loads), accumulation in fp64.
+// input value is loaded once and feeds up to 8 fp64 FMAs.  The wave's 8 weight rows are first spread into a
+// zero-padded window in LDS (indexed by input row), so the inner loop is branch-free: one coalesced load,
+// 8 broadcast LDS reads, 8 FMAs.
+constexpr int kVWin = 96;  // max input rows spanned by 8 consecutive outputs (8*f + K), checked on the host
 __global__ __launch_bounds__(kBlock) void ica_resample_v_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                                 int planes, int W, BandOp op) {
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  __shared__ double wz[kWaves][kOutsV][kVWin];
+  const int lane = threadIdx.x & 63;
+  const int x = blockIdx.x * 64 + lane;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int o0 = (blockIdx.y * kWaves + wave) * kOutsV;
   const int pl = blockIdx.z;
-  if (o0 >= op.n_out) return;
+  if (o0 >= op.n_out) return;  // whole wave
   const int no = min(kOutsV, op.n_out - o0);
-  int st[kOutsV];
-#pragma unroll
-  for (int i = 0; i < kOutsV; ++i) st[i] = op.start[min(o0 + i, op.n_out - 1)];
-  const int j0 = st[0];
-  const int j1 = min(op.n_in, st[no - 1] + op.K);
+  const int j0 = op.start[o0];
+  const int j1 = min(op.n_in, op.start[o0 + no - 1] + op.K);
+  const int span = j1 - j0;    // <= kVWin
+  for (int idx = lane; idx < kOutsV * kVWin; idx += 64) {
+    const int i = idx / kVWin, jj = idx - i * kVWin;
+    double v = 0.0;
+    if (i < no) {
+      const int k = j0 + jj - op.start[o0 + i];
+      if (k >= 0 && k < op.K) v = op.w[(size_t)(o0 + i) * op.K + k];
+    }
+    wz[wave][i][jj] = v;
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's own LDS writes (no cross-wave sharing)
+  __builtin_amdgcn_wave_barrier();
   double acc[kOutsV];
 #pragma unroll
   for (int i = 0; i < kOutsV; ++i) acc[i] = 0.0;
   const bool xin = x < W;
-  const float* col = in + (size_t)pl * op.n_in * W + (xin ? x : 0);
-  for (int j = j0; j < j1; ++j) {
-    const double v = xin ? (double)col[(size_t)j * W] : 0.0;
+  const float* col = in + (size_t)pl * op.n_in * W + (size_t)j0 * W + (xin ? x : 0);
+  for (int jj = 0; jj < span; ++jj) {
+    const double v = (double)col[(size_t)jj * W];
 #pragma unroll
-    for (int i = 0; i < kOutsV; ++i) {
-      const int k = j - st[i];
-      if (i < no && k >= 0 && k < op.K) acc[i] = fma(op.w[(size_t)(o0 + i) * op.K + k], v, acc[i]);
-    }
+    for (int i = 0; i < kOutsV; ++i) acc[i] = fma(wz[wave][i][jj], v, acc[i]);
   }
   if (xin) {
 #pragma unroll
