@@ -41,11 +41,14 @@ struct DevBuf {
 };
 
 struct DeviceBandOp {
-  DevBuf start, w, wT;
+  DevBuf start, wT, vj0, vspan, vw;
   int n_in = 0, n_out = 0, K = 0;
   int span_pad = 0;  // LDS row pitch (floats) of the horizontal pass: widest 64-output input span, made odd
-  int vspan = 0;     // widest input span of 8 consecutive outputs (vertical pass window)
-  BandOp view() const { return BandOp{start.as<int>(), w.as<double>(), wT.as<double>(), n_in, n_out, K}; }
+  int vspan_max = 0; // widest input span of 8 consecutive outputs (vertical pass window)
+  BandOp view() const {
+    return BandOp{start.as<int>(), wT.as<float>(), vj0.as<int>(), vspan.as<int>(), vw.as<float>(), n_in, n_out, K};
+  }
+  void release() { start.release(); wT.release(); vj0.release(); vspan.release(); vw.release(); }
 };
 
 struct LevelGeom {
@@ -71,9 +74,7 @@ struct ica_ctx {
   std::vector<hipEvent_t> ev_pool;
   ~ica_ctx() {
     for (auto& kv : ops) {
-      kv.second->start.release();
-      kv.second->w.release();
-      kv.second->wT.release();
+      kv.second->release();
       delete kv.second;
     }
     for (auto e : ev_pool) (void)hipEventDestroy(e);
@@ -144,9 +145,9 @@ int get_op(ica_ctx* ctx, int n_in, int n_out, DeviceBandOp** out) {
     return ICA_OK;
   }
   HostBandOp h = build_rescale_op(n_in, n_out);
-  std::vector<double> wT((size_t)h.K * n_out);
+  std::vector<float> wT((size_t)h.K * n_out);
   for (int o = 0; o < n_out; ++o)
-    for (int k = 0; k < h.K; ++k) wT[(size_t)k * n_out + o] = h.w[(size_t)o * h.K + k];
+    for (int k = 0; k < h.K; ++k) wT[(size_t)k * n_out + o] = (float)h.w[(size_t)o * h.K + k];
   auto* d = new DeviceBandOp();
   d->n_in = n_in;
   d->n_out = n_out;
@@ -154,19 +155,35 @@ int get_op(ica_ctx* ctx, int n_in, int n_out, DeviceBandOp** out) {
   int span = 1;
   for (int o = 0; o < n_out; o += 64) span = std::max(span, h.start[std::min(o + 63, n_out - 1)] + h.K - h.start[o]);
   d->span_pad = span | 1;
-  for (int o = 0; o < n_out; o += kOutsV)
-    d->vspan = std::max(d->vspan, std::min(n_in, h.start[std::min(o + kOutsV - 1, n_out - 1)] + h.K) - h.start[o]);
-  hipError_t e = d->start.ensure(h.start.size() * sizeof(int));
-  if (e == hipSuccess) e = d->w.ensure(h.w.size() * sizeof(double));
-  if (e == hipSuccess) e = d->wT.ensure(wT.size() * sizeof(double));
-  if (e == hipSuccess) e = hipMemcpy(d->start.ptr, h.start.data(), h.start.size() * sizeof(int), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(d->w.ptr, h.w.data(), h.w.size() * sizeof(double), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(d->wT.ptr, wT.data(), wT.size() * sizeof(double), hipMemcpyHostToDevice);
+  // vertical pass: per group of 8 outputs, a zero-padded window of weights indexed by input row
+  const int groups = (n_out + kOutsV - 1) / kOutsV;
+  std::vector<int> vj0(groups), vspan(groups);
+  std::vector<float> vw((size_t)groups * kVWin * kOutsV, 0.0f);
+  for (int g = 0; g < groups; ++g) {
+    const int o0 = g * kOutsV, no = std::min(kOutsV, n_out - o0);
+    vj0[g] = h.start[o0];
+    vspan[g] = std::min(n_in, h.start[o0 + no - 1] + h.K) - vj0[g];
+    d->vspan_max = std::max(d->vspan_max, vspan[g]);
+    if (vspan[g] > kVWin) continue;  // rejected by the caller
+    for (int i = 0; i < no; ++i)
+      for (int k = 0; k < h.K; ++k) {
+        const int jj = h.start[o0 + i] + k - vj0[g];
+        if (jj >= 0 && jj < vspan[g]) vw[((size_t)g * kVWin + jj) * kOutsV + i] = (float)h.w[(size_t)(o0 + i) * h.K + k];
+      }
+  }
+  auto up = [&](DevBuf& b, const void* src, size_t bytes) -> hipError_t {
+    hipError_t e = b.ensure(bytes);
+    if (e == hipSuccess) e = hipMemcpy(b.ptr, src, bytes, hipMemcpyHostToDevice);
+    return e;
+  };
+  hipError_t e = up(d->start, h.start.data(), h.start.size() * sizeof(int));
+  if (e == hipSuccess) e = up(d->wT, wT.data(), wT.size() * sizeof(float));
+  if (e == hipSuccess) e = up(d->vj0, vj0.data(), vj0.size() * sizeof(int));
+  if (e == hipSuccess) e = up(d->vspan, vspan.data(), vspan.size() * sizeof(int));
+  if (e == hipSuccess) e = up(d->vw, vw.data(), vw.size() * sizeof(float));
   if (e != hipSuccess) {
     ctx->last_error = std::string("pyramid operator upload: ") + hipGetErrorString(e);
-    d->start.release();
-    d->w.release();
-    d->wT.release();
+    d->release();
     delete d;
     return e == hipErrorOutOfMemory ? ICA_ENOMEM : ICA_EHIP;
   }
@@ -187,19 +204,19 @@ int launch_minmax(ica_ctx* ctx, int batch, size_t elems, const float* img, float
   return ICA_OK;
 }
 
-int launch_pyramid_down(ica_ctx* ctx, int batch, int C, int H, int W, int h, int w, const float* in, float* out) {
+// `mm` = [batch][2] min/max of `in` (the clip range of skimage's rescale), already computed on the stream
+int launch_pyramid_down(ica_ctx* ctx, int batch, int C, int H, int W, int h, int w, const float* in, float* out,
+                        const float* mm) {
   DeviceBandOp *ox = nullptr, *oy = nullptr;
   ICA_TRY(get_op(ctx, W, w, &ox));
   ICA_TRY(get_op(ctx, H, h, &oy));
   const int planes = batch * C;
   const size_t lds = (size_t)kRowsH * ox->span_pad * sizeof(float);
-  if (lds > 64 * 1024 || oy->vspan > kVWin) {
+  if (lds > 64 * 1024 || oy->vspan_max > kVWin) {
     ctx->last_error = "pyramid step: downsampling factor too large for the LDS-tiled horizontal pass";
     return ICA_EINVAL_ARG;
   }
   ICA_HIP(ctx, ctx->tmp_resample.ensure((size_t)planes * h * W * sizeof(float)));
-  ICA_HIP(ctx, ctx->mm_in.ensure((size_t)batch * 2 * sizeof(float)));
-  ICA_TRY(launch_minmax(ctx, batch, (size_t)C * H * W, in, ctx->mm_in.as<float>()));
   float* tmp = ctx->tmp_resample.as<float>();
   // planes ride on grid.z (<= 65535): chunk on whole pairs so the clip range index stays aligned
   const int step = std::max(C, (32768 / C) * C);
@@ -209,7 +226,7 @@ int launch_pyramid_down(ica_ctx* ctx, int batch, int C, int H, int W, int h, int
                        dim3(kBlock), 0, ctx->stream, in + (size_t)p0 * H * W, tmp + (size_t)p0 * h * W, np, W, oy->view());
     hipLaunchKernelGGL(ica_resample_h_kernel, dim3((w + 63) / 64, (h + kRowsH - 1) / kRowsH, np), dim3(kBlock), lds,
                        ctx->stream, tmp + (size_t)p0 * h * W, out + (size_t)p0 * h * w, np, C, h, ox->view(),
-                       ctx->mm_in.as<float>() + (size_t)(p0 / C) * 2, ox->span_pad);
+                       mm + (size_t)(p0 / C) * 2, ox->span_pad);
   }
   ICA_HIP(ctx, hipGetLastError());
   return ICA_OK;
@@ -282,7 +299,8 @@ int ensure_state(ica_ctx* ctx, const ica_problem* pr, const LevelGeom* g) {
   ICA_HIP(ctx, ctx->lists.ensure(3 * B * sizeof(int)));
   ICA_HIP(ctx, ctx->counts.ensure(4 * sizeof(int)));
   ICA_HIP(ctx, ctx->count_hist.ensure((size_t)pr->nscales * std::max(1, pr->max_iter) * sizeof(int)));
-  ICA_HIP(ctx, ctx->minmax.ensure(B * 2 * sizeof(float)));
+  ICA_HIP(ctx, ctx->minmax.ensure((size_t)pr->nscales * B * 2 * sizeof(float)));
+  ICA_HIP(ctx, ctx->mm_in.ensure(B * 2 * sizeof(float)));
   for (int s = 1; s < pr->nscales; ++s) {
     const size_t bytes = B * pr->channels * g[s].H * g[s].W * sizeof(float);
     ICA_HIP(ctx, ctx->pyr1[s].ensure(bytes));
@@ -404,12 +422,23 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
   const float* L2[ICA_MAX_SCALES];
   L1[0] = I1;
   L2[0] = I2;
+  // min/max of every I2 level is needed twice (clip range of the next pyramid step and of the warp at that level):
+  // computed once per level into mm2[s]
+  ICA_HIP(ctx, ctx->minmax.ensure((size_t)ns * B * 2 * sizeof(float)));
+  ICA_HIP(ctx, ctx->mm_in.ensure((size_t)B * 2 * sizeof(float)));
+  float* mm2 = ctx->minmax.as<float>();
   for (int s = 1; s < ns; ++s) {
-    ICA_TRY(launch_pyramid_down(ctx, B, C, g[s - 1].H, g[s - 1].W, g[s].H, g[s].W, L1[s - 1], ctx->pyr1[s].as<float>()));
-    ICA_TRY(launch_pyramid_down(ctx, B, C, g[s - 1].H, g[s - 1].W, g[s].H, g[s].W, L2[s - 1], ctx->pyr2[s].as<float>()));
+    const size_t elems = (size_t)C * g[s - 1].H * g[s - 1].W;
+    ICA_TRY(launch_minmax(ctx, B, elems, L1[s - 1], ctx->mm_in.as<float>()));
+    ICA_TRY(launch_pyramid_down(ctx, B, C, g[s - 1].H, g[s - 1].W, g[s].H, g[s].W, L1[s - 1], ctx->pyr1[s].as<float>(),
+                                ctx->mm_in.as<float>()));
+    ICA_TRY(launch_minmax(ctx, B, elems, L2[s - 1], mm2 + (size_t)(s - 1) * B * 2));
+    ICA_TRY(launch_pyramid_down(ctx, B, C, g[s - 1].H, g[s - 1].W, g[s].H, g[s].W, L2[s - 1], ctx->pyr2[s].as<float>(),
+                                mm2 + (size_t)(s - 1) * B * 2));
     L1[s] = ctx->pyr1[s].as<float>();
     L2[s] = ctx->pyr2[s].as<float>();
   }
+  ICA_TRY(launch_minmax(ctx, B, (size_t)C * g[ns - 1].H * g[ns - 1].W, L2[ns - 1], mm2 + (size_t)(ns - 1) * B * 2));
   ICA_HIP(ctx, hipMemsetAsync(ctx->count_hist.ptr, 0, (size_t)ns * std::max(1, max_iter) * sizeof(int), st));
   if (trace_out)
     ICA_HIP(ctx, hipMemsetAsync(trace_out, 0, (size_t)B * ns * max_iter * ICA_TRACE_STRIDE * sizeof(double), st));
@@ -433,7 +462,6 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
 
   // ---- coarse to fine (ref :340-372) ----
   for (int s = ns - 1; s >= 0; --s) {
-    ICA_TRY(launch_minmax(ctx, B, (size_t)C * g[s].H * g[s].W, L2[s], ctx->minmax.as<float>()));
     LevelInitArgs li{};
     li.batch = B; li.tt = tt; li.level = s; li.nscales = ns;
     if (s < ns - 1) { li.w_coarse = g[s + 1].W; li.h_coarse = g[s + 1].H; li.w_fine = g[s].W; li.h_fine = g[s].H; }
@@ -446,7 +474,7 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
     la.I1 = L1[s]; la.I2 = L2[s]; la.H = g[s].H; la.W = g[s].W;
     la.tiles_x = g[s].tiles_x; la.tiles_y = g[s].tiles_y; la.tile_h = g[s].tile_h;
     la.delta = pr->delta; la.nanif = pr->nanifoutside; la.robust_type = pr->robust_type;
-    la.p = p; la.lambda_it = ctx->lambda_it.as<double>(); la.minmax = ctx->minmax.as<float>();
+    la.p = p; la.lambda_it = ctx->lambda_it.as<double>(); la.minmax = mm2 + (size_t)s * B * 2;
     la.partials = ctx->partials.as<double>();
 
     if (!robust) {  // ref :96-103: steepest-descent Hessian and its inverse, once per level
@@ -497,7 +525,7 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
   if (DI_out || Iw_out) {
     // Iw / DI of the last executed iteration at scale 0 = warp under the parameters BEFORE the last
     // update (ref :111-114 then :123, returned at :133).  minmax still holds the scale-0 range.
-    ICA_TRY(launch_warp(ctx, B, C, g[0].H, g[0].W, tt, I2, ctx->p_prev.as<double>(), ctx->minmax.as<float>(), I1,
+    ICA_TRY(launch_warp(ctx, B, C, g[0].H, g[0].W, tt, I2, ctx->p_prev.as<double>(), mm2, I1,
                         Iw_out, DI_out));
   }
   ICA_HIP(ctx, hipGetLastError());
@@ -647,7 +675,9 @@ int ica_op_pyramid_down_dev(ica_ctx* ctx, int batch, int channels, int height, i
   if (!ctx || !in || !out || batch <= 0 || channels <= 0 || height <= 0 || width <= 0 || !(nu > 0)) return ICA_EINVAL_ARG;
   ICA_HIP(ctx, hipSetDevice(ctx->device));
   const int w = std::max(1, round_half_even(width * nu)), h = std::max(1, round_half_even(height * nu));
-  return launch_pyramid_down(ctx, batch, channels, height, width, h, w, in, out);
+  ICA_HIP(ctx, ctx->mm_in.ensure((size_t)batch * 2 * sizeof(float)));
+  ICA_TRY(launch_minmax(ctx, batch, (size_t)channels * height * width, in, ctx->mm_in.as<float>()));
+  return launch_pyramid_down(ctx, batch, channels, height, width, h, w, in, out, ctx->mm_in.as<float>());
 }
 
 int ica_op_zoom_in_parameters_dev(ica_ctx* ctx, int batch, int tt, int w, int h, int ww, int hh, double* p) {

@@ -535,64 +535,56 @@ __global__ void ica_zoom_params_kernel(int batch, int tt, int w, int h, int ww, 
 //      operator per axis on the host, see ica_pyramid.hpp) ------------------------------------------
 struct BandOp {
   const int* start;    // [n_out] first input index of the band
-  const double* w;     // [n_out][K]
-  const double* wT;    // [K][n_out] (same weights, transposed for lane-contiguous reads)
+  const float* wT;     // [K][n_out] weights, transposed for lane-contiguous reads (horizontal pass)
+  const int* vj0;      // [groups] first input row of each group of 8 outputs (vertical pass)
+  const int* vspan;    // [groups] input rows spanned by the group
+  const float* vw;     // [groups][kVWin][8] zero-padded weight window, 8 outputs interleaved
   int n_in, n_out, K;
 };
 
 constexpr int kOutsV = 8;    // consecutive output rows per wave in the vertical pass
 constexpr int kRowsH = 32;   // rows per workgroup in the horizontal pass (8 per wave)
+constexpr int kVWin = 96;    // max input rows spanned by 8 consecutive outputs (8*f + K), checked on the host
 
 // Vertical pass: in [planes][n_in][W] -> out [planes][n_out][W].
-// lane = column (coalesced 256-B row segments); each wave produces 8 consecutive output rows, so every
-// input value is loaded once and feeds up to 8 fp64 FMAs.  The wave's 8 weight rows are first spread into a
-// zero-padded window in LDS (indexed by input row), so the inner loop is branch-free: one coalesced load,
-// 8 broadcast LDS reads, 8 FMAs.
-constexpr int kVWin = 96;  // max input rows spanned by 8 consecutive outputs (8*f + K), checked on the host
+// lane = column (coalesced 256-B row segments); each wave produces 8 consecutive output rows, so every input
+// value is loaded once and feeds 8 FMAs whose weights are wave-uniform: they come through the scalar cache into
+// SGPRs (one s_load_dwordx8 per input row), the vector ALU only sees v_fmac(acc, sgpr, value).
+// The operator weights are float64 on the host (ica_pyramid.hpp); they are applied in fp32 like every other
+// per-pixel quantity of the engine (the result is stored as fp32 anyway).
 __global__ __launch_bounds__(kBlock) void ica_resample_v_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                                 int planes, int W, BandOp op) {
-  __shared__ double wz[kWaves][kOutsV][kVWin];
   const int lane = threadIdx.x & 63;
   const int x = blockIdx.x * 64 + lane;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int o0 = (blockIdx.y * kWaves + wave) * kOutsV;
+  const int g = blockIdx.y * kWaves + wave;
+  const int o0 = g * kOutsV;
   const int pl = blockIdx.z;
   if (o0 >= op.n_out) return;  // whole wave
   const int no = min(kOutsV, op.n_out - o0);
-  const int j0 = op.start[o0];
-  const int j1 = min(op.n_in, op.start[o0 + no - 1] + op.K);
-  const int span = j1 - j0;    // <= kVWin
-  for (int idx = lane; idx < kOutsV * kVWin; idx += 64) {
-    const int i = idx / kVWin, jj = idx - i * kVWin;
-    double v = 0.0;
-    if (i < no) {
-      const int k = j0 + jj - op.start[o0 + i];
-      if (k >= 0 && k < op.K) v = op.w[(size_t)(o0 + i) * op.K + k];
-    }
-    wz[wave][i][jj] = v;
-  }
-  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's own LDS writes (no cross-wave sharing)
-  __builtin_amdgcn_wave_barrier();
-  double acc[kOutsV];
+  const int j0 = op.vj0[g], span = op.vspan[g];
+  const float* __restrict__ wz = op.vw + (size_t)g * kVWin * kOutsV;
+  float acc[kOutsV];
 #pragma unroll
-  for (int i = 0; i < kOutsV; ++i) acc[i] = 0.0;
+  for (int i = 0; i < kOutsV; ++i) acc[i] = 0.f;
   const bool xin = x < W;
   const float* col = in + (size_t)pl * op.n_in * W + (size_t)j0 * W + (xin ? x : 0);
+#pragma unroll 4
   for (int jj = 0; jj < span; ++jj) {
-    const double v = (double)col[(size_t)jj * W];
+    const float v = col[(size_t)jj * W];
 #pragma unroll
-    for (int i = 0; i < kOutsV; ++i) acc[i] = fma(wz[wave][i][jj], v, acc[i]);
+    for (int i = 0; i < kOutsV; ++i) acc[i] = fmaf(wz[jj * kOutsV + i], v, acc[i]);
   }
   if (xin) {
 #pragma unroll
     for (int i = 0; i < kOutsV; ++i)
-      if (i < no) out[((size_t)pl * op.n_out + o0 + i) * W + x] = (float)acc[i];
+      if (i < no) out[((size_t)pl * op.n_out + o0 + i) * W + x] = acc[i];
   }
 }
 
 // Horizontal pass + clip: in [planes][H][n_in] -> out [planes][H][n_out].
 // A workgroup stages 32 rows x (input span of 64 outputs) in LDS with coalesced loads; lane = output column,
-// each thread accumulates 8 rows so one (coalesced, transposed) weight load feeds 8 fp64 FMAs.
+// each thread accumulates 8 rows so one (coalesced, transposed) weight load feeds 8 FMAs.
 __global__ __launch_bounds__(kBlock) void ica_resample_h_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                                 int planes, int channels, int H, BandOp op,
                                                                 const float* __restrict__ minmax, int span_pad) {
@@ -612,21 +604,22 @@ __global__ __launch_bounds__(kBlock) void ica_resample_h_kernel(const float* __r
   const int o = o_base + lane;
   if (o >= op.n_out) return;
   const int s = op.start[o] - c0;
-  double acc[8];
+  float acc[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] = 0.0;
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
   const float* t0 = tile + (rg * 8) * span_pad + s;
+#pragma unroll 2
   for (int k = 0; k < op.K; ++k) {
-    const double wk = op.wT[(size_t)k * op.n_out + o];
+    const float wk = op.wT[(size_t)k * op.n_out + o];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = fma(wk, (double)t0[i * span_pad + k], acc[i]);
+    for (int i = 0; i < 8; ++i) acc[i] = fmaf(wk, t0[i * span_pad + k], acc[i]);
   }
   const int pair = pl / channels;
   const float lo = minmax[pair * 2], hi = minmax[pair * 2 + 1];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int y = r_base + rg * 8 + i;
-    if (y < H) out[((size_t)pl * H + y) * op.n_out + o] = fminf(fmaxf((float)acc[i], lo), hi);
+    if (y < H) out[((size_t)pl * H + y) * op.n_out + o] = fminf(fmaxf(acc[i], lo), hi);
   }
 }
 
