@@ -70,15 +70,13 @@ def main():
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    from inverse_compositional_algorithm_amd import sharding
+    info = sharding.rank_info()
+    world, rank, local = info.world, info.rank, info.local_rank
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    sharding.init("nccl", info)  # backend "nccl" is RCCL on ROCm; used for the barrier and 3 scalars only
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
@@ -90,7 +88,7 @@ def main():
     torch.cuda.set_device(local)
     B, H, W, C = cfg["batch"], cfg["H"], cfg["W"], cfg["C"]
     # each rank owns its own shard of pairs, generated on its own device (no host staging, no exchange)
-    I1, I2, p_gt = eng.make_batch(1000 * args.config + 7919 * rank, B, H, W, C, cfg["transform"],
+    I1, I2, p_gt = eng.make_batch(sharding.shard_seed(args.config, rank), B, H, W, C, cfg["transform"],
                                   robust_clutter=cfg["robust"] != 0)
     prob = eng.problem(B, H, W, C, cfg["transform"], cfg["robust"], nscales=cfg["nscales"], nu=0.5, tol=1e-3,
                        lambda_=0.0, nanifoutside=True, delta=10)
@@ -98,9 +96,7 @@ def main():
     eng.set_profiling(True)  # HIP events around every fused-iteration launch, on the stream it runs on
 
     def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        sharding.barrier(info, eng.device)
 
     for _ in range(args.warmup):
         res = eng.solve(I1, I2, prob, want_stats=True)
@@ -125,13 +121,7 @@ def main():
     perr = (res.p[:, :n] - p_gt[:, :n]).abs().amax(dim=1)
     converged = float((res.error < 1e-3).double().mean())
 
-    t_max = torch.tensor([dt], dtype=torch.float64, device=eng.device)
-    tot = torch.tensor([float(units), float(B * args.steps)], dtype=torch.float64, device=eng.device)
-    if world > 1:
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    dt = float(t_max[0])
-    units_all, pairs_all = float(tot[0]), float(tot[1])
+    dt, units_all, pairs_all = sharding.aggregate(info, dt, float(units), float(B * args.steps), eng.device)
 
     if rank == 0:
         dom_ms, dom_bytes, dom_n = lvl_ms[0], lvl_bytes[0], lvl_launch[0]
@@ -176,9 +166,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    sharding.finalize(info)
 
 
 if __name__ == "__main__":

@@ -132,12 +132,21 @@ __global__ __launch_bounds__(kBlock) void ica_accumulate2_kernel(LevelArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
   
 
-  int pair = blockIdx.y;
+  // XCD-aware block -> (pair, tile) map.  Workgroups are dealt round-robin to the 8 XCDs (blocks b and b+8 share
+  // an L2), so consecutive block ids take different PAIRS and the blocks that share an XCD walk through the tiles
+  // of the same pair: tile halos and the rows two chunks share are then served by that XCD's L2.  (Placement is a
+  // speed matter only; nothing depends on it for correctness.)
+  const int ntiles = a.tiles_x * a.tiles_y;
+  const int slot = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+  const int pair_slot = (slot / ntiles) * 8 + xcd;
+  const int tile_id = slot - (slot / ntiles) * ntiles;
+  int pair = pair_slot;
   if (a.act_list) {
-    if ((int)blockIdx.y >= *a.act_count) return;
-    pair = a.act_list[blockIdx.y];
+    if (pair_slot >= *a.act_count) return;
+    pair = a.act_list[pair_slot];
+  } else if (pair_slot >= a.n_pairs) {
+    return;
   }
-  const int tile_id = blockIdx.x;
   const int tx = tile_id % a.tiles_x, ty = tile_id / a.tiles_x;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

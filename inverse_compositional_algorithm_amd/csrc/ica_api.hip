@@ -243,10 +243,12 @@ void launch_accumulate_c(int C, dim3 grid, hipStream_t st, const LevelArgs& a) {
     else
       hipLaunchKernelGGL((ica_accumulate_kernel<TT, MODE, 3>), grid, dim3(kBlock), 0, st, a);
   } else {
+    // 1-D grid: (pairs rounded up to a multiple of 8) x tiles, decoded XCD-aware inside the kernel
+    const dim3 g1((unsigned)(((grid.y + 7) / 8) * 8 * grid.x));
     if (C == 1)
-      hipLaunchKernelGGL((ica_accumulate2_kernel<TT, MODE, 1>), grid, dim3(kBlock), 0, st, a);
+      hipLaunchKernelGGL((ica_accumulate2_kernel<TT, MODE, 1>), g1, dim3(kBlock), 0, st, a);
     else
-      hipLaunchKernelGGL((ica_accumulate2_kernel<TT, MODE, 3>), grid, dim3(kBlock), 0, st, a);
+      hipLaunchKernelGGL((ica_accumulate2_kernel<TT, MODE, 3>), g1, dim3(kBlock), 0, st, a);
   }
 }
 
@@ -476,6 +478,7 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
     la.delta = pr->delta; la.nanif = pr->nanifoutside; la.robust_type = pr->robust_type;
     la.p = p; la.lambda_it = ctx->lambda_it.as<double>(); la.minmax = mm2 + (size_t)s * B * 2;
     la.partials = ctx->partials.as<double>();
+    la.n_pairs = B;
 
     if (!robust) {  // ref :96-103: steepest-descent Hessian and its inverse, once per level
       la.act_list = nullptr; la.act_count = nullptr;
@@ -642,6 +645,7 @@ int ica_op_normal_equations_dev(ica_ctx* ctx, const ica_problem* pr, const float
   la.delta = pr->delta; la.nanif = pr->nanifoutside; la.robust_type = pr->robust_type;
   la.p = p; la.lambda_it = lambda_it; la.minmax = ctx->minmax.as<float>();
   la.partials = ctx->partials.as<double>();
+  la.n_pairs = B;
   la.act_list = nullptr; la.act_count = nullptr;
   if (robust) {
     launch_accumulate_mode(kModeRobust, tt, C, dim3(g[0].tiles, B), ctx->stream, la);

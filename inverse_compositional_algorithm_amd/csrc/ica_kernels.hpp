@@ -28,8 +28,9 @@ struct LevelArgs {
   const double* p;          // [B][8]
   const double* lambda_it;  // [B]
   const float* minmax;      // [B][2] clip range of I2 at this level
-  const int* act_list;      // current active pairs (nullptr: pair = blockIdx.y)
+  const int* act_list;      // current active pairs (nullptr: pair index = slot)
   const int* act_count;
+  int n_pairs;              // pairs covered by this launch (bound when act_list == nullptr)
   double* partials;         // [B][tiles][kAccStride]
 };
 
