@@ -574,7 +574,7 @@ __global__ __launch_bounds__(kBlock) void ica_accumulate2_kernel(LevelArgs a) {
     val += __shfl_down(val, 2, 64);
     val += __shfl_down(val, 1, 64);
     if (q == 0 && have) {
-      double* out = a.partials + ((size_t)pair * (a.tiles_x * a.tiles_y) + tile_id) * kAccStride;
+      double* out = a.partials + ((size_t)pair_slot * ntiles + tile_id) * kAccStride;  // indexed by launch slot
       out[e < N ? e : kMaxN + (e - N)] = val;
     }
   }

@@ -41,14 +41,16 @@ struct DevBuf {
 };
 
 struct DeviceBandOp {
-  DevBuf start, wT, vj0, vspan, vw;
+  DevBuf start, wT, vj0, vspan, vown0, vown1, vw;
   int n_in = 0, n_out = 0, K = 0;
-  int span_pad = 0;  // LDS row pitch (floats) of the horizontal pass: widest 64-output input span, made odd
-  int vspan_max = 0; // widest input span of 8 consecutive outputs (vertical pass window)
+  int vspan_max = 0;   // widest input span of 8 consecutive outputs (window of both passes)
+  int span_pad = 0;    // LDS row pitch (floats) of the horizontal pass: widest 64-output input span, made odd
+  bool vcover = false; // the groups' "own" ranges cover the whole input axis (min/max can be folded into the pass)
   BandOp view() const {
-    return BandOp{start.as<int>(), wT.as<float>(), vj0.as<int>(), vspan.as<int>(), vw.as<float>(), n_in, n_out, K};
+    return BandOp{start.as<int>(), wT.as<float>(), vj0.as<int>(), vspan.as<int>(), vown0.as<int>(), vown1.as<int>(),
+                  vw.as<float>(), n_in, n_out, K};
   }
-  void release() { start.release(); wT.release(); vj0.release(); vspan.release(); vw.release(); }
+  void release() { start.release(); wT.release(); vj0.release(); vspan.release(); vown0.release(); vown1.release(); vw.release(); }
 };
 
 struct LevelGeom {
@@ -115,6 +117,22 @@ int validate(const ica_problem* pr) {
   return ICA_OK;
 }
 
+// Tile height for a launch over `pairs` pairs: the tallest tile (taller tiles amortise the per-tile fold) that still
+// gives the launch >= ~4 workgroups per CU.  Late iterations, when only a few pairs are still iterating, therefore
+// use short tiles and spread those pairs over the whole chip instead of running 16 long workgroups per pair.
+void set_tiling(LevelGeom& g, int pairs) {
+  g.tiles_x = (g.W + kTileW - 1) / kTileW;
+  int th = 256;
+  while (th > 16) {
+    const long blocks = (long)pairs * g.tiles_x * ((g.H + th - 1) / th);
+    if (blocks >= 1024 && th <= std::max(16, g.H)) break;
+    th >>= 1;
+  }
+  g.tile_h = th;
+  g.tiles_y = (g.H + th - 1) / th;
+  g.tiles = g.tiles_x * g.tiles_y;
+}
+
 void level_sizes(const ica_problem* pr, LevelGeom* g) {
   g[0].W = pr->width;
   g[0].H = pr->height;
@@ -122,19 +140,7 @@ void level_sizes(const ica_problem* pr, LevelGeom* g) {
     g[s].W = std::max(1, round_half_even(g[s - 1].W * pr->nu));
     g[s].H = std::max(1, round_half_even(g[s - 1].H * pr->nu));
   }
-  for (int s = 0; s < pr->nscales; ++s) {
-    g[s].tiles_x = (g[s].W + kTileW - 1) / kTileW;
-    // the tallest tile that still leaves >= ~8 workgroups per CU; taller tiles amortise the reduction
-    int th = 256;
-    while (th > 32) {
-      const long blocks = (long)pr->batch * g[s].tiles_x * ((g[s].H + th - 1) / th);
-      if (blocks >= 2048 && th <= std::max(32, g[s].H)) break;
-      th >>= 1;
-    }
-    g[s].tile_h = th;
-    g[s].tiles_y = (g[s].H + th - 1) / th;
-    g[s].tiles = g[s].tiles_x * g[s].tiles_y;
-  }
+  for (int s = 0; s < pr->nscales; ++s) set_tiling(g[s], pr->batch);
 }
 
 int get_op(ica_ctx* ctx, int n_in, int n_out, DeviceBandOp** out) {
@@ -152,9 +158,6 @@ int get_op(ica_ctx* ctx, int n_in, int n_out, DeviceBandOp** out) {
   d->n_in = n_in;
   d->n_out = n_out;
   d->K = h.K;
-  int span = 1;
-  for (int o = 0; o < n_out; o += 64) span = std::max(span, h.start[std::min(o + 63, n_out - 1)] + h.K - h.start[o]);
-  d->span_pad = span | 1;
   // vertical pass: per group of 8 outputs, a zero-padded window of weights indexed by input row
   const int groups = (n_out + kOutsV - 1) / kOutsV;
   std::vector<int> vj0(groups), vspan(groups);
@@ -171,6 +174,21 @@ int get_op(ica_ctx* ctx, int n_in, int n_out, DeviceBandOp** out) {
         if (jj >= 0 && jj < vspan[g]) vw[((size_t)g * kVWin + jj) * kOutsV + i] = (float)h.w[(size_t)(o0 + i) * h.K + k];
       }
   }
+  // partition of the input axis among the groups (for the fused min/max): cut at the middle of each overlap
+  std::vector<int> vown0(groups), vown1(groups);
+  d->vcover = vj0[0] == 0 && vj0[groups - 1] + vspan[groups - 1] == n_in;
+  for (int g = 0; g < groups; ++g) {
+    vown0[g] = g == 0 ? vj0[0] : (vj0[g] + vj0[g - 1] + vspan[g - 1] + 1) / 2;
+    vown1[g] = g == groups - 1 ? vj0[g] + vspan[g] : (vj0[g + 1] + vj0[g] + vspan[g] + 1) / 2;
+    if (g > 0 && vj0[g] > vj0[g - 1] + vspan[g - 1]) d->vcover = false;  // a gap between windows
+  }
+  for (int g = 0; g < groups; ++g)
+    if (vown0[g] < vj0[g] || vown1[g] > vj0[g] + vspan[g] || vown1[g] < vown0[g]) d->vcover = false;
+  {
+    int span = 1;
+    for (int o = 0; o < n_out; o += 64) span = std::max(span, h.start[std::min(o + 63, n_out - 1)] + h.K - h.start[o]);
+    d->span_pad = span | 1;
+  }
   auto up = [&](DevBuf& b, const void* src, size_t bytes) -> hipError_t {
     hipError_t e = b.ensure(bytes);
     if (e == hipSuccess) e = hipMemcpy(b.ptr, src, bytes, hipMemcpyHostToDevice);
@@ -180,6 +198,8 @@ int get_op(ica_ctx* ctx, int n_in, int n_out, DeviceBandOp** out) {
   if (e == hipSuccess) e = up(d->wT, wT.data(), wT.size() * sizeof(float));
   if (e == hipSuccess) e = up(d->vj0, vj0.data(), vj0.size() * sizeof(int));
   if (e == hipSuccess) e = up(d->vspan, vspan.data(), vspan.size() * sizeof(int));
+  if (e == hipSuccess) e = up(d->vown0, vown0.data(), vown0.size() * sizeof(int));
+  if (e == hipSuccess) e = up(d->vown1, vown1.data(), vown1.size() * sizeof(int));
   if (e == hipSuccess) e = up(d->vw, vw.data(), vw.size() * sizeof(float));
   if (e != hipSuccess) {
     ctx->last_error = std::string("pyramid operator upload: ") + hipGetErrorString(e);
@@ -204,29 +224,46 @@ int launch_minmax(ica_ctx* ctx, int batch, size_t elems, const float* img, float
   return ICA_OK;
 }
 
-// `mm` = [batch][2] min/max of `in` (the clip range of skimage's rescale), already computed on the stream
+// One pyramid step.  `mm_out` ([batch][2]) receives the min/max of `in` (the clip range of skimage's rescale, and --
+// for I2 -- of the warp at that level); it is folded into the vertical pass, which reads every pixel of `in` anyway.
 int launch_pyramid_down(ica_ctx* ctx, int batch, int C, int H, int W, int h, int w, const float* in, float* out,
-                        const float* mm) {
+                        float* mm_out) {
   DeviceBandOp *ox = nullptr, *oy = nullptr;
   ICA_TRY(get_op(ctx, W, w, &ox));
   ICA_TRY(get_op(ctx, H, h, &oy));
   const int planes = batch * C;
   const size_t lds = (size_t)kRowsH * ox->span_pad * sizeof(float);
   if (lds > 64 * 1024 || oy->vspan_max > kVWin) {
-    ctx->last_error = "pyramid step: downsampling factor too large for the LDS-tiled horizontal pass";
+    ctx->last_error = "pyramid step: downsampling factor too large for the tiled resampling passes";
     return ICA_EINVAL_ARG;
   }
   ICA_HIP(ctx, ctx->tmp_resample.ensure((size_t)planes * h * W * sizeof(float)));
   float* tmp = ctx->tmp_resample.as<float>();
-  // planes ride on grid.z (<= 65535): chunk on whole pairs so the clip range index stays aligned
+  const int vgroups = (h + kOutsV - 1) / kOutsV, xblocks = (W + 63) / 64;
+  const int per_pair = C * vgroups * xblocks;  // min/max partials per pair written by the vertical pass
+  float* part = nullptr;
+  if (oy->vcover) {
+    ICA_HIP(ctx, ctx->mm_part.ensure((size_t)batch * per_pair * 2 * sizeof(float)));
+    part = ctx->mm_part.as<float>();
+  } else {
+    ICA_TRY(launch_minmax(ctx, batch, (size_t)C * H * W, in, mm_out));
+  }
+  // planes ride on grid.z (<= 65535): chunk on whole pairs so the per-pair indices stay aligned
   const int step = std::max(C, (32768 / C) * C);
   for (int p0 = 0; p0 < planes; p0 += step) {
     const int np = std::min(step, planes - p0);
-    hipLaunchKernelGGL(ica_resample_v_kernel, dim3((W + 63) / 64, (h + kWaves * kOutsV - 1) / (kWaves * kOutsV), np),
-                       dim3(kBlock), 0, ctx->stream, in + (size_t)p0 * H * W, tmp + (size_t)p0 * h * W, np, W, oy->view());
+    hipLaunchKernelGGL(ica_resample_v_kernel, dim3(xblocks, (vgroups + kWaves - 1) / kWaves, np), dim3(kBlock), 0, ctx->stream,
+                       in + (size_t)p0 * H * W, tmp + (size_t)p0 * h * W, np, C, W, oy->view(),
+                       part ? part + (size_t)p0 * vgroups * xblocks * 2 : nullptr);
+  }
+  if (part)
+    hipLaunchKernelGGL(ica_minmax_final_kernel, dim3((batch + 255) / 256), dim3(256), 0, ctx->stream, part, per_pair, batch,
+                       mm_out);
+  for (int p0 = 0; p0 < planes; p0 += step) {
+    const int np = std::min(step, planes - p0);
     hipLaunchKernelGGL(ica_resample_h_kernel, dim3((w + 63) / 64, (h + kRowsH - 1) / kRowsH, np), dim3(kBlock), lds,
                        ctx->stream, tmp + (size_t)p0 * h * W, out + (size_t)p0 * h * w, np, C, h, ox->view(),
-                       mm + (size_t)(p0 / C) * 2, ox->span_pad);
+                       mm_out + (size_t)(p0 / C) * 2, ox->span_pad);
   }
   ICA_HIP(ctx, hipGetLastError());
   return ICA_OK;
@@ -290,9 +327,16 @@ int launch_warp(ica_ctx* ctx, int batch, int C, int H, int W, int tt, const floa
 
 int ensure_state(ica_ctx* ctx, const ica_problem* pr, const LevelGeom* g) {
   const size_t B = (size_t)pr->batch;
-  int max_tiles = 1;
-  for (int s = 0; s < pr->nscales; ++s) max_tiles = std::max(max_tiles, g[s].tiles);
-  ICA_HIP(ctx, ctx->partials.ensure(B * max_tiles * kAccStride * sizeof(double)));
+  size_t max_slots_tiles = 1;  // largest (pairs in a launch) x (tiles per pair) over every launch geometry
+  for (int s = 0; s < pr->nscales; ++s)
+    for (int nb = 1; nb <= pr->batch; nb = (nb < pr->batch && nb * 2 > pr->batch) ? pr->batch : nb * 2) {
+      LevelGeom t = g[s];
+      set_tiling(t, nb);
+      // the tiling is chosen for the polled count, which can only over-estimate the pairs of later launches
+      max_slots_tiles = std::max(max_slots_tiles, (size_t)std::min<long>(pr->batch, 2L * nb) * t.tiles);
+      if (nb == pr->batch) break;
+    }
+  ICA_HIP(ctx, ctx->partials.ensure(max_slots_tiles * kAccStride * sizeof(double)));
   ICA_HIP(ctx, ctx->hinv.ensure(B * 64 * sizeof(double)));
   ICA_HIP(ctx, ctx->p_prev.ensure(B * 8 * sizeof(double)));
   ICA_HIP(ctx, ctx->lambda_it.ensure(B * sizeof(double)));
@@ -430,11 +474,8 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
   ICA_HIP(ctx, ctx->mm_in.ensure((size_t)B * 2 * sizeof(float)));
   float* mm2 = ctx->minmax.as<float>();
   for (int s = 1; s < ns; ++s) {
-    const size_t elems = (size_t)C * g[s - 1].H * g[s - 1].W;
-    ICA_TRY(launch_minmax(ctx, B, elems, L1[s - 1], ctx->mm_in.as<float>()));
     ICA_TRY(launch_pyramid_down(ctx, B, C, g[s - 1].H, g[s - 1].W, g[s].H, g[s].W, L1[s - 1], ctx->pyr1[s].as<float>(),
                                 ctx->mm_in.as<float>()));
-    ICA_TRY(launch_minmax(ctx, B, elems, L2[s - 1], mm2 + (size_t)(s - 1) * B * 2));
     ICA_TRY(launch_pyramid_down(ctx, B, C, g[s - 1].H, g[s - 1].W, g[s].H, g[s].W, L2[s - 1], ctx->pyr2[s].as<float>(),
                                 mm2 + (size_t)(s - 1) * B * 2));
     L1[s] = ctx->pyr1[s].as<float>();
@@ -483,13 +524,16 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
     if (!robust) {  // ref :96-103: steepest-descent Hessian and its inverse, once per level
       la.act_list = nullptr; la.act_count = nullptr;
       launch_accumulate_mode(kModeHessian, tt, C, dim3(g[s].tiles, B), st, la);
-      hipLaunchKernelGGL(ica_setup_solve_kernel, dim3(B), dim3(64), 0, st, la.partials, g[s].tiles, n,
+      hipLaunchKernelGGL(ica_setup_solve_kernel, dim3(B), dim3(kSolveThreads), 0, st, la.partials, g[s].tiles, n,
                          ctx->hinv.as<double>());
     }
 
     int nb = B;  // upper bound of the number of active pairs
+    LevelGeom lg = g[s];
     for (int it = 0; it < max_iter && nb > 0; ++it) {
       const int cur = it % 3, nxt = (it + 1) % 3, clr = (it + 2) % 3;
+      set_tiling(lg, nb);  // accumulate and solve of one iteration always agree on the tiling
+      la.tiles_x = lg.tiles_x; la.tiles_y = lg.tiles_y; la.tile_h = lg.tile_h;
       la.act_list = lists + (size_t)cur * B;
       la.act_count = counts + cur;
       size_t e0 = 0, e1 = 0;
@@ -497,7 +541,7 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
         ICA_TRY(next_event(&e0));
         ICA_HIP(ctx, hipEventRecord(ctx->ev_pool[e0], st));
       }
-      launch_accumulate_mode(robust ? kModeRobust : kModeL2, tt, C, dim3(g[s].tiles, nb), st, la);
+      launch_accumulate_mode(robust ? kModeRobust : kModeL2, tt, C, dim3(lg.tiles, nb), st, la);
       if (ctx->profiling) {
         ICA_TRY(next_event(&e1));
         ICA_HIP(ctx, hipEventRecord(ctx->ev_pool[e1], st));
@@ -505,7 +549,7 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
       }
       launches[s]++;
       SolveArgs sa{};
-      sa.tt = tt; sa.n = n; sa.robust = robust; sa.flags = pr->flags; sa.tiles = g[s].tiles; sa.max_iter = max_iter;
+      sa.tt = tt; sa.n = n; sa.robust = robust; sa.flags = pr->flags; sa.tiles = lg.tiles; sa.max_iter = max_iter;
       sa.level = s; sa.nscales = ns; sa.iter = it; sa.tol = pr->tol; sa.lambda_user = pr->lambda;
       sa.lambdaN = pr->lambdaN; sa.lambda_ratio = pr->lambda_ratio;
       sa.partials = la.partials; sa.p = p; sa.p_prev = ctx->p_prev.as<double>(); sa.Hinv = ctx->hinv.as<double>();
@@ -513,7 +557,7 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
       sa.cur_list = lists + (size_t)cur * B; sa.cur_count = counts + cur;
       sa.nxt_list = lists + (size_t)nxt * B; sa.nxt_count = counts + nxt; sa.clr_count = counts + clr;
       sa.count_hist = ctx->count_hist.as<int>(); sa.trace = trace_out;
-      hipLaunchKernelGGL(ica_solve_kernel, dim3(nb), dim3(64), 0, st, sa);
+      hipLaunchKernelGGL(ica_solve_kernel, dim3(nb), dim3(kSolveThreads), 0, st, sa);
       if ((it + 1) % ctx->poll_every == 0 && it + 1 < max_iter) {
         // shrink the grid to the pairs that are still iterating (the count only ever decreases)
         ICA_HIP(ctx, hipMemcpyAsync(ctx->pinned_count, counts + nxt, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -649,14 +693,14 @@ int ica_op_normal_equations_dev(ica_ctx* ctx, const ica_problem* pr, const float
   la.act_list = nullptr; la.act_count = nullptr;
   if (robust) {
     launch_accumulate_mode(kModeRobust, tt, C, dim3(g[0].tiles, B), ctx->stream, la);
-    hipLaunchKernelGGL(ica_gather_normal_equations_kernel, dim3(B), dim3(64), 0, ctx->stream, la.partials, g[0].tiles, n,
+    hipLaunchKernelGGL(ica_gather_normal_equations_kernel, dim3(B), dim3(kSolveThreads), 0, ctx->stream, la.partials, g[0].tiles, n,
                        B, 1, 1, (const double*)nullptr, H_out, b_out);
   } else {
     launch_accumulate_mode(kModeHessian, tt, C, dim3(g[0].tiles, B), ctx->stream, la);
-    hipLaunchKernelGGL(ica_gather_normal_equations_kernel, dim3(B), dim3(64), 0, ctx->stream, la.partials, g[0].tiles, n,
+    hipLaunchKernelGGL(ica_gather_normal_equations_kernel, dim3(B), dim3(kSolveThreads), 0, ctx->stream, la.partials, g[0].tiles, n,
                        B, 0, 1, (const double*)nullptr, H_out, b_out);
     launch_accumulate_mode(kModeL2, tt, C, dim3(g[0].tiles, B), ctx->stream, la);
-    hipLaunchKernelGGL(ica_gather_normal_equations_kernel, dim3(B), dim3(64), 0, ctx->stream, la.partials, g[0].tiles, n,
+    hipLaunchKernelGGL(ica_gather_normal_equations_kernel, dim3(B), dim3(kSolveThreads), 0, ctx->stream, la.partials, g[0].tiles, n,
                        B, 1, 0, (const double*)nullptr, H_out, b_out);
   }
   ICA_HIP(ctx, hipGetLastError());
@@ -680,7 +724,6 @@ int ica_op_pyramid_down_dev(ica_ctx* ctx, int batch, int channels, int height, i
   ICA_HIP(ctx, hipSetDevice(ctx->device));
   const int w = std::max(1, round_half_even(width * nu)), h = std::max(1, round_half_even(height * nu));
   ICA_HIP(ctx, ctx->mm_in.ensure((size_t)batch * 2 * sizeof(float)));
-  ICA_TRY(launch_minmax(ctx, batch, (size_t)channels * height * width, in, ctx->mm_in.as<float>()));
   return launch_pyramid_down(ctx, batch, channels, height, width, h, w, in, out, ctx->mm_in.as<float>());
 }
 

@@ -7,6 +7,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "ica_math.hpp"
 
 namespace ica {
@@ -31,7 +33,7 @@ struct LevelArgs {
   const int* act_list;      // current active pairs (nullptr: pair index = slot)
   const int* act_count;
   int n_pairs;              // pairs covered by this launch (bound when act_list == nullptr)
-  double* partials;         // [B][tiles][kAccStride]
+  double* partials;         // [slot][tiles][kAccStride]; slot = index into the active list (= pair without a list)
 };
 
 template <int TT> struct NP;
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(kBlock) void ica_accumulate_kernel(LevelArgs a) {
     }
   }
   __syncthreads();
-  double* out = a.partials + ((size_t)pair * (a.tiles_x * a.tiles_y) + tile) * kAccStride;
+  double* out = a.partials + ((size_t)blockIdx.y * (a.tiles_x * a.tiles_y) + tile) * kAccStride;
   const int t = threadIdx.x;
   if (kB && t < N) out[t] = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
   if (kH && t >= kMaxN && t < kMaxN + NT) out[t] = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
@@ -297,33 +299,50 @@ struct SolveArgs {
   double* trace;          // nullable [B][nscales][max_iter][10]
 };
 
-// Sum the tile partials of one pair in tile order (deterministic), lanes 0..43 one accumulator each.
-__device__ __forceinline__ void gather_partials(const double* partials, int pair, int tiles, double* s /*LDS[44]*/) {
-  const int k = threadIdx.x;
-  if (k < kAccStride) {
-    const double* q = partials + (size_t)pair * tiles * kAccStride + k;
-    double acc = 0.0;
-    for (int t = 0; t < tiles; ++t) acc += q[(size_t)t * kAccStride];
-    s[k] = acc;
+// Sum the tile partials of one launch slot in a fixed order (deterministic): 256 threads = 4 groups x 64 lanes;
+// lane k < 44 of group g adds tiles g, g+4, g+8, ... of accumulator k (4 loads in flight), then the 4 group sums are
+// added in group order.  Only accumulators [k_lo, k_hi) are touched.
+constexpr int kSolveThreads = 256;
+__device__ __forceinline__ void gather_partials(const double* partials, int slot, int tiles, double* s /*LDS[44]*/,
+                                                int k_lo = 0, int k_hi = kAccStride) {
+  __shared__ double part[4][kAccStride];
+  const int k = threadIdx.x & 63, g = threadIdx.x >> 6;
+  if (k >= k_lo && k < k_hi) {
+    const double* q = partials + (size_t)slot * tiles * kAccStride + k;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int t = g;
+    for (; t + 12 < tiles; t += 16) {
+      a0 += q[(size_t)t * kAccStride];
+      a1 += q[(size_t)(t + 4) * kAccStride];
+      a2 += q[(size_t)(t + 8) * kAccStride];
+      a3 += q[(size_t)(t + 12) * kAccStride];
+    }
+    for (; t < tiles; t += 4) a0 += q[(size_t)t * kAccStride];
+    part[g][k] = (a0 + a1) + (a2 + a3);
+  }
+  __syncthreads();
+  if (threadIdx.x < kAccStride) {
+    const int kk = threadIdx.x;
+    s[kk] = (kk >= k_lo && kk < k_hi) ? ((part[0][kk] + part[1][kk]) + part[2][kk]) + part[3][kk] : 0.0;
   }
   __syncthreads();
 }
 
 // L2 setup: H^-1 once per level (ref :102-103).
-__global__ __launch_bounds__(64) void ica_setup_solve_kernel(const double* partials, int tiles, int n, double* Hinv) {
+__global__ __launch_bounds__(kSolveThreads) void ica_setup_solve_kernel(const double* partials, int tiles, int n, double* Hinv) {
   __shared__ double s[kAccStride];
   const int pair = blockIdx.x;
-  gather_partials(partials, pair, tiles, s);
+  gather_partials(partials, pair, tiles, s, kMaxN, kAccStride);
+  __shared__ double Hm[kMaxN * kMaxN], ws[kLuWork];
   if (threadIdx.x == 0) {
-    double Hm[kMaxN * kMaxN];
     for (int k = 0; k < n; ++k)
       for (int m = k; m < n; ++m) Hm[k * kMaxN + m] = Hm[m * kMaxN + k] = s[kMaxN + tri_index(k, m, n)];
-    lu_inverse(n, Hm, Hinv + (size_t)pair * 64, kMaxN);
+    lu_inverse(n, Hm, Hinv + (size_t)pair * 64, kMaxN, ws);
   }
 }
 
 // Solve + compositional update + loop control for one active pair (ref :117-131 / :233-259).
-__global__ __launch_bounds__(64) void ica_solve_kernel(SolveArgs a) {
+__global__ __launch_bounds__(kSolveThreads) void ica_solve_kernel(SolveArgs a) {
   __shared__ double s[kAccStride];
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     *a.clr_count = 0;
@@ -331,15 +350,15 @@ __global__ __launch_bounds__(64) void ica_solve_kernel(SolveArgs a) {
   }
   if ((int)blockIdx.x >= *a.cur_count) return;
   const int pair = a.cur_list[blockIdx.x];
-  gather_partials(a.partials, pair, a.tiles, s);
+  gather_partials(a.partials, blockIdx.x, a.tiles, s, 0, a.robust ? kAccStride : kMaxN);  // indexed by launch slot
+  __shared__ double Hm[kMaxN * kMaxN], Hi[kMaxN * kMaxN], ws[kLuWork];
   if (threadIdx.x != 0) return;
   const int n = a.n;
-  double Hm[kMaxN * kMaxN], Hi[kMaxN * kMaxN];
   const double* hinv = a.Hinv + (size_t)pair * 64;
   if (a.robust) {
     for (int k = 0; k < n; ++k)
       for (int m = k; m < n; ++m) Hm[k * kMaxN + m] = Hm[m * kMaxN + k] = s[kMaxN + tri_index(k, m, n)];
-    lu_inverse(n, Hm, Hi, kMaxN);  // derivatives.py:110-130 (zeros if singular)
+    lu_inverse(n, Hm, Hi, kMaxN, ws);  // derivatives.py:110-130 (zeros if singular)
     hinv = Hi;
   }
   double dp[kMaxN], e2 = 0.0;
@@ -512,8 +531,8 @@ __global__ void ica_solve_update_kernel(int batch, int tt, int flags, const doub
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= batch) return;
   const int n = nparams_of(tt);
-  double Hi[64];
-  lu_inverse(n, H + (size_t)i * 64, Hi, 8);
+  double Hi[64], ws[kLuWork];  // test hook: one matrix per thread, private workspace
+  lu_inverse(n, H + (size_t)i * 64, Hi, 8, ws);
   double dp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, e2 = 0.0;
   for (int r = 0; r < n; ++r) {
     double v = 0.0;
@@ -536,25 +555,28 @@ __global__ void ica_zoom_params_kernel(int batch, int tt, int w, int h, int ww, 
 //      operator per axis on the host, see ica_pyramid.hpp) ------------------------------------------
 struct BandOp {
   const int* start;    // [n_out] first input index of the band
-  const float* wT;     // [K][n_out] weights, transposed for lane-contiguous reads (horizontal pass)
-  const int* vj0;      // [groups] first input row of each group of 8 outputs (vertical pass)
-  const int* vspan;    // [groups] input rows spanned by the group
+  const float* wT;     // [K][n_out] weights (horizontal pass of the generic fallback)
+  const int* vj0;      // [groups] first input index of each group of 8 outputs
+  const int* vspan;    // [groups] input samples spanned by the group
+  const int* vown0;    // [groups] the groups' windows overlap; [vown0, vown1) partitions the input axis so that the
+  const int* vown1;    //          vertical pass can fold the image's min/max into its single read
   const float* vw;     // [groups][kVWin][8] zero-padded weight window, 8 outputs interleaved
   int n_in, n_out, K;
 };
 
-constexpr int kOutsV = 8;    // consecutive output rows per wave in the vertical pass
+constexpr int kOutsV = 8;    // consecutive outputs per wave in both passes
+constexpr int kVWin = 96;    // max input samples spanned by 8 consecutive outputs (8*f + K), checked on the host
 constexpr int kRowsH = 32;   // rows per workgroup in the horizontal pass (8 per wave)
-constexpr int kVWin = 96;    // max input rows spanned by 8 consecutive outputs (8*f + K), checked on the host
 
-// Vertical pass: in [planes][n_in][W] -> out [planes][n_out][W].
+// Vertical pass: in [planes][n_in][W] -> out [planes][n_out][W]  (+ optional min/max of `in` per pair).
 // lane = column (coalesced 256-B row segments); each wave produces 8 consecutive output rows, so every input
 // value is loaded once and feeds 8 FMAs whose weights are wave-uniform: they come through the scalar cache into
-// SGPRs (one s_load_dwordx8 per input row), the vector ALU only sees v_fmac(acc, sgpr, value).
+// SGPRs (s_load_dwordx8/x16 per input row), the vector ALU only sees v_fmac / v_pk_fma(acc, sgpr, value).
 // The operator weights are float64 on the host (ica_pyramid.hpp); they are applied in fp32 like every other
 // per-pixel quantity of the engine (the result is stored as fp32 anyway).
 __global__ __launch_bounds__(kBlock) void ica_resample_v_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                                int planes, int W, BandOp op) {
+                                                                int planes, int channels, int W, BandOp op,
+                                                                float* __restrict__ mm_part) {
   const int lane = threadIdx.x & 63;
   const int x = blockIdx.x * 64 + lane;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -564,22 +586,44 @@ __global__ __launch_bounds__(kBlock) void ica_resample_v_kernel(const float* __r
   if (o0 >= op.n_out) return;  // whole wave
   const int no = min(kOutsV, op.n_out - o0);
   const int j0 = op.vj0[g], span = op.vspan[g];
+  const int own0 = mm_part ? op.vown0[g] - j0 : 0, own1 = mm_part ? op.vown1[g] - j0 : 0;
   const float* __restrict__ wz = op.vw + (size_t)g * kVWin * kOutsV;
   float acc[kOutsV];
 #pragma unroll
   for (int i = 0; i < kOutsV; ++i) acc[i] = 0.f;
   const bool xin = x < W;
   const float* col = in + (size_t)pl * op.n_in * W + (size_t)j0 * W + (xin ? x : 0);
+  float lo = INFINITY, hi = -INFINITY;
+  auto run = [&](int a, int b, auto track_c) {  // rows [a, b) of the window; track_c: fold them into min/max
+    constexpr bool TRACK = decltype(track_c)::value;
 #pragma unroll 4
-  for (int jj = 0; jj < span; ++jj) {
-    const float v = col[(size_t)jj * W];
+    for (int jj = a; jj < b; ++jj) {
+      const float v = col[(size_t)jj * W];
+      if constexpr (TRACK) { lo = fminf(lo, v); hi = fmaxf(hi, v); }
 #pragma unroll
-    for (int i = 0; i < kOutsV; ++i) acc[i] = fmaf(wz[jj * kOutsV + i], v, acc[i]);
-  }
+      for (int i = 0; i < kOutsV; ++i) acc[i] = fmaf(wz[jj * kOutsV + i], v, acc[i]);
+    }
+  };
+  run(0, own0, std::false_type{});
+  run(own0, own1, std::true_type{});
+  run(own1, span, std::false_type{});
   if (xin) {
 #pragma unroll
     for (int i = 0; i < kOutsV; ++i)
       if (i < no) out[((size_t)pl * op.n_out + o0 + i) * W + x] = acc[i];
+  }
+  if (mm_part) {  // one partial per wave, reduced by ica_minmax_final_kernel (no atomics: 256 waves share a pair)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      lo = fminf(lo, __shfl_down(lo, off, 64));
+      hi = fmaxf(hi, __shfl_down(hi, off, 64));
+    }
+    if (lane == 0) {
+      const int ngroups = (op.n_out + kOutsV - 1) / kOutsV;
+      const size_t slot = ((size_t)pl * ngroups + g) * gridDim.x + blockIdx.x;  // [plane][group][column block]
+      mm_part[slot * 2] = lo;
+      mm_part[slot * 2 + 1] = hi;
+    }
   }
 }
 

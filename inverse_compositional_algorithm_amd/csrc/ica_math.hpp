@@ -159,28 +159,32 @@ __host__ __device__ inline void zoom_in_parameters(double* p, int tt, int w, int
 // then solve against the identity (dgesv).  Returns false -- and Hinv = 0 -- when a pivot is exactly
 // zero, which is when LAPACK reports the matrix singular and the reference falls back to zeros.
 // H and Hinv are n x n, row stride `ld`.
-__host__ __device__ inline bool lu_inverse(int n, const double* H, double* Hinv, int ld) {
-  double a[kMaxN][kMaxN];
-  int piv[kMaxN];
+// `ws` is a caller-provided workspace of kLuWork doubles (LDS in the kernels: private arrays with run-time
+// indices would live in scratch memory).
+constexpr int kLuWork = kMaxN * kMaxN + 2 * kMaxN;
+__host__ __device__ inline bool lu_inverse(int n, const double* H, double* Hinv, int ld, double* ws) {
+  double* a = ws;                        // [n][kMaxN]
+  double* x = ws + kMaxN * kMaxN;        // [kMaxN]
+  double* pivd = x + kMaxN;              // [kMaxN] pivot rows (stored as doubles: exact small integers)
   for (int i = 0; i < n; ++i)
-    for (int j = 0; j < n; ++j) a[i][j] = H[i * ld + j];
+    for (int j = 0; j < n; ++j) a[i * kMaxN + j] = H[i * ld + j];
   bool ok = true;
   for (int k = 0; k < n; ++k) {
     int pr = k;
-    double best = fabs(a[k][k]);
+    double best = fabs(a[k * kMaxN + k]);
     for (int i = k + 1; i < n; ++i) {
-      const double v = fabs(a[i][k]);
+      const double v = fabs(a[i * kMaxN + k]);
       if (v > best) { best = v; pr = i; }
     }
-    piv[k] = pr;
+    pivd[k] = (double)pr;
     if (pr != k)
-      for (int j = 0; j < n; ++j) { const double t = a[k][j]; a[k][j] = a[pr][j]; a[pr][j] = t; }
-    if (a[k][k] == 0.0) { ok = false; continue; }
-    const double r = 1.0 / a[k][k];
-    for (int i = k + 1; i < n; ++i) a[i][k] *= r;
+      for (int j = 0; j < n; ++j) { const double t = a[k * kMaxN + j]; a[k * kMaxN + j] = a[pr * kMaxN + j]; a[pr * kMaxN + j] = t; }
+    if (a[k * kMaxN + k] == 0.0) { ok = false; continue; }
+    const double r = 1.0 / a[k * kMaxN + k];
+    for (int i = k + 1; i < n; ++i) a[i * kMaxN + k] *= r;
     for (int i = k + 1; i < n; ++i) {
-      const double l = a[i][k];
-      for (int j = k + 1; j < n; ++j) a[i][j] -= l * a[k][j];
+      const double l = a[i * kMaxN + k];
+      for (int j = k + 1; j < n; ++j) a[i * kMaxN + j] -= l * a[k * kMaxN + j];
     }
   }
   if (!ok) {
@@ -189,19 +193,20 @@ __host__ __device__ inline bool lu_inverse(int n, const double* H, double* Hinv,
     return false;
   }
   for (int c = 0; c < n; ++c) {
-    double x[kMaxN];
     for (int i = 0; i < n; ++i) x[i] = (i == c) ? 1.0 : 0.0;
-    for (int k = 0; k < n; ++k)
-      if (piv[k] != k) { const double t = x[k]; x[k] = x[piv[k]]; x[piv[k]] = t; }
+    for (int k = 0; k < n; ++k) {
+      const int pk = (int)pivd[k];
+      if (pk != k) { const double t = x[k]; x[k] = x[pk]; x[pk] = t; }
+    }
     for (int i = 1; i < n; ++i) {  // L y = P e_c (unit lower)
-      double s = x[i];
-      for (int j = 0; j < i; ++j) s -= a[i][j] * x[j];
-      x[i] = s;
+      double sum = x[i];
+      for (int j = 0; j < i; ++j) sum -= a[i * kMaxN + j] * x[j];
+      x[i] = sum;
     }
     for (int i = n - 1; i >= 0; --i) {  // U x = y
-      double s = x[i];
-      for (int j = i + 1; j < n; ++j) s -= a[i][j] * x[j];
-      x[i] = s / a[i][i];
+      double sum = x[i];
+      for (int j = i + 1; j < n; ++j) sum -= a[i * kMaxN + j] * x[j];
+      x[i] = sum / a[i * kMaxN + i];
     }
     for (int i = 0; i < n; ++i) Hinv[i * ld + c] = x[i];
   }
