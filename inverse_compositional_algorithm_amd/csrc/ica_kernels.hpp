@@ -629,20 +629,26 @@ __global__ __launch_bounds__(kBlock) void ica_resample_v_kernel(const float* __r
 
 // Horizontal pass + clip: in [planes][H][n_in] -> out [planes][H][n_out].
 // A workgroup stages 32 rows x (input span of 64 outputs) in LDS with coalesced loads; lane = output column,
-// each thread accumulates 8 rows so one (coalesced, transposed) weight load feeds 8 FMAs.
+// each thread accumulates 8 rows so one (coalesced, transposed) weight load feeds 8 FMAs.  The staged rows are
+// stored de-interleaved (even input columns, then odd ones): with a decimation factor of 2 consecutive lanes
+// read input columns 2 apart, which this layout turns into consecutive LDS words (no 2-way bank conflict); any
+// other factor is still correct, only less regular.
 __global__ __launch_bounds__(kBlock) void ica_resample_h_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                                 int planes, int channels, int H, BandOp op,
                                                                 const float* __restrict__ minmax, int span_pad) {
-  extern __shared__ float tile[];  // [kRowsH][span_pad]
+  extern __shared__ float tile[];  // [kRowsH][span_pad]: per row, even columns at [0, half), odd ones at [half, ...)
   const int o_base = blockIdx.x * 64, r_base = blockIdx.y * kRowsH, pl = blockIdx.z;
   const int o_last = min(o_base + 63, op.n_out - 1);
   const int c0 = op.start[o_base];
   const int span = op.start[o_last] + op.K - c0;  // <= span_pad
+  const int half = (span_pad + 1) >> 1;
   const float* src = in + (size_t)pl * H * op.n_in;
-  for (int idx = threadIdx.x; idx < kRowsH * span; idx += kBlock) {
-    const int r = idx / span, c = idx - r * span;
-    const int y = r_base + r, xg = c0 + c;
-    tile[r * span_pad + c] = (y < H && xg < op.n_in) ? src[(size_t)y * op.n_in + xg] : 0.0f;
+  for (int r = threadIdx.x >> 6; r < kRowsH; r += kWaves) {
+    const int y = r_base + r;
+    for (int c = threadIdx.x & 63; c < span; c += 64) {
+      const int xg = c0 + c;
+      tile[r * span_pad + (c & 1) * half + (c >> 1)] = (y < H && xg < op.n_in) ? src[(size_t)y * op.n_in + xg] : 0.0f;
+    }
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
@@ -652,12 +658,14 @@ __global__ __launch_bounds__(kBlock) void ica_resample_h_kernel(const float* __r
   float acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-  const float* t0 = tile + (rg * 8) * span_pad + s;
+  const float* t0 = tile + (rg * 8) * span_pad;
 #pragma unroll 2
   for (int k = 0; k < op.K; ++k) {
     const float wk = op.wT[(size_t)k * op.n_out + o];
+    const int c = s + k;
+    const float* q = t0 + (c & 1) * half + (c >> 1);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = fmaf(wk, t0[i * span_pad + k], acc[i]);
+    for (int i = 0; i < 8; ++i) acc[i] = fmaf(wk, q[i * span_pad], acc[i]);
   }
   const int pair = pl / channels;
   const float lo = minmax[pair * 2], hi = minmax[pair * 2 + 1];
