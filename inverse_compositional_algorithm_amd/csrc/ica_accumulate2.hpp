@@ -142,6 +142,9 @@ __global__ __launch_bounds__(kBlock) void ica_accumulate2_kernel(LevelArgs a) {
   const int tile_id = slot - (slot / ntiles) * ntiles;
   int pair = pair_slot;
   if (a.act_list) {
+    // tell the host how many pairs entered this iteration (it sizes the next launch from it, without a sync)
+    if (a.host_slot && blockIdx.x == 0 && threadIdx.x == 0)
+      __hip_atomic_store(a.host_slot, *a.act_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (pair_slot >= *a.act_count) return;
     pair = a.act_list[pair_slot];
   } else if (pair_slot >= a.n_pairs) {

@@ -71,7 +71,11 @@ struct ica_ctx {
   DevBuf tmp_resample;                                // intermediate of the separable pyramid pass
   DevBuf partials, hinv, p_prev, lambda_it, error, niter, lists, counts, count_hist, minmax, mm_part, mm_in;
   DevBuf scratch_p;
-  int* pinned_count = nullptr;
+  int* pinned_count = nullptr;   // 4 ints for synchronous reads + a [scales][max_iter] board the kernels post to
+  int* board = nullptr;          // host pointer of the board (pinned, host-coherent)
+  int* board_dev = nullptr;      // device pointer of the same memory
+  size_t board_cap = 0;
+  bool board_dirty = false;      // kernels of an earlier call may still post to the board
   std::map<std::pair<int, int>, DeviceBandOp*> ops;
   std::vector<hipEvent_t> ev_pool;
   ~ica_ctx() {
@@ -85,6 +89,7 @@ struct ica_ctx {
                      &count_hist, &minmax, &mm_part, &mm_in, &scratch_p};
     for (auto* b : all) b->release();
     if (pinned_count) (void)hipHostFree(pinned_count);
+    if (board) (void)hipHostFree(board);
   }
 };
 
@@ -122,10 +127,11 @@ int validate(const ica_problem* pr) {
 // use short tiles and spread those pairs over the whole chip instead of running 16 long workgroups per pair.
 void set_tiling(LevelGeom& g, int pairs) {
   g.tiles_x = (g.W + kTileW - 1) / kTileW;
-  int th = 256;
+  int th = 512;   // (at most 64 chunks of 16 rows per tile: one lane plans one chunk)
+  if (const char* e = getenv("ICA_MAX_TILE_H")) th = std::max(16, atoi(e));
   while (th > 16) {
     const long blocks = (long)pairs * g.tiles_x * ((g.H + th - 1) / th);
-    if (blocks >= 1024 && th <= std::max(16, g.H)) break;
+    if (blocks >= 2048 && th <= std::max(16, g.H)) break;
     th >>= 1;
   }
   g.tile_h = th;
@@ -358,6 +364,13 @@ int ensure_state(ica_ctx* ctx, const ica_problem* pr, const LevelGeom* g) {
   if (pr->nscales > 1)
     ICA_HIP(ctx, ctx->tmp_resample.ensure(B * pr->channels * g[1].H * g[0].W * sizeof(float)));
   if (!ctx->pinned_count) ICA_HIP(ctx, hipHostMalloc((void**)&ctx->pinned_count, 4 * sizeof(int), hipHostMallocDefault));
+  const size_t need = (size_t)pr->nscales * std::max(1, pr->max_iter);
+  if (need > ctx->board_cap) {
+    if (ctx->board) { ICA_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipHostFree(ctx->board); ctx->board = nullptr; }
+    ICA_HIP(ctx, hipHostMalloc((void**)&ctx->board, need * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
+    ICA_HIP(ctx, hipHostGetDevicePointer((void**)&ctx->board_dev, ctx->board, 0));
+    ctx->board_cap = need;
+  }
   return ICA_OK;
 }
 
@@ -482,6 +495,9 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
     L2[s] = ctx->pyr2[s].as<float>();
   }
   ICA_TRY(launch_minmax(ctx, B, (size_t)C * g[ns - 1].H * g[ns - 1].W, L2[ns - 1], mm2 + (size_t)(ns - 1) * B * 2));
+  if (ctx->board_dirty) ICA_HIP(ctx, hipStreamSynchronize(st));  // nothing may post to the board while it is reset
+  for (size_t i = 0; i < (size_t)ns * std::max(1, max_iter); ++i) ctx->board[i] = -1;
+  ctx->board_dirty = true;
   ICA_HIP(ctx, hipMemsetAsync(ctx->count_hist.ptr, 0, (size_t)ns * std::max(1, max_iter) * sizeof(int), st));
   if (trace_out)
     ICA_HIP(ctx, hipMemsetAsync(trace_out, 0, (size_t)B * ns * max_iter * ICA_TRACE_STRIDE * sizeof(double), st));
@@ -522,7 +538,7 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
     la.n_pairs = B;
 
     if (!robust) {  // ref :96-103: steepest-descent Hessian and its inverse, once per level
-      la.act_list = nullptr; la.act_count = nullptr;
+      la.act_list = nullptr; la.act_count = nullptr; la.host_slot = nullptr;
       launch_accumulate_mode(kModeHessian, tt, C, dim3(g[s].tiles, B), st, la);
       hipLaunchKernelGGL(ica_setup_solve_kernel, dim3(B), dim3(kSolveThreads), 0, st, la.partials, g[s].tiles, n,
                          ctx->hinv.as<double>());
@@ -532,17 +548,33 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
     LevelGeom lg = g[s];
     for (int it = 0; it < max_iter && nb > 0; ++it) {
       const int cur = it % 3, nxt = (it + 1) % 3, clr = (it + 2) % 3;
+      if (it >= 1) {
+        // The fused kernel of iteration it-1 posts "pairs that entered it-1" to host-visible memory when it starts;
+        // that is an upper bound for iteration `it`.  Waiting for it keeps the host exactly one iteration ahead of
+        // the GPU -- the queue never runs dry and no stream synchronisation is needed.
+        volatile int* slot = ctx->board + (size_t)s * max_iter + (it - 1);
+        int v = *slot, spins = 0;
+        while (v < 0 && spins < 200000000) { v = *slot; ++spins; }
+        if (v < 0) {  // should not happen: fall back to a synchronous read
+          ICA_HIP(ctx, hipMemcpyAsync(ctx->pinned_count, counts + cur, sizeof(int), hipMemcpyDeviceToHost, st));
+          ICA_HIP(ctx, hipStreamSynchronize(st));
+          v = ctx->pinned_count[0];
+        }
+        nb = std::min(nb, v);
+        if (nb == 0) break;
+      }
+      la.host_slot = ctx->board_dev + (size_t)s * max_iter + it;
       set_tiling(lg, nb);  // accumulate and solve of one iteration always agree on the tiling
       la.tiles_x = lg.tiles_x; la.tiles_y = lg.tiles_y; la.tile_h = lg.tile_h;
       la.act_list = lists + (size_t)cur * B;
       la.act_count = counts + cur;
       size_t e0 = 0, e1 = 0;
-      if (ctx->profiling) {
+      if (ctx->profiling && s == 0) {  // the kernel quoted in the roofline: scale 0
         ICA_TRY(next_event(&e0));
         ICA_HIP(ctx, hipEventRecord(ctx->ev_pool[e0], st));
       }
       launch_accumulate_mode(robust ? kModeRobust : kModeL2, tt, C, dim3(lg.tiles, nb), st, la);
-      if (ctx->profiling) {
+      if (ctx->profiling && s == 0) {
         ICA_TRY(next_event(&e1));
         ICA_HIP(ctx, hipEventRecord(ctx->ev_pool[e1], st));
         evrecs.push_back({s, e0, e1});
@@ -558,12 +590,6 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
       sa.nxt_list = lists + (size_t)nxt * B; sa.nxt_count = counts + nxt; sa.clr_count = counts + clr;
       sa.count_hist = ctx->count_hist.as<int>(); sa.trace = trace_out;
       hipLaunchKernelGGL(ica_solve_kernel, dim3(nb), dim3(kSolveThreads), 0, st, sa);
-      if ((it + 1) % ctx->poll_every == 0 && it + 1 < max_iter) {
-        // shrink the grid to the pairs that are still iterating (the count only ever decreases)
-        ICA_HIP(ctx, hipMemcpyAsync(ctx->pinned_count, counts + nxt, sizeof(int), hipMemcpyDeviceToHost, st));
-        ICA_HIP(ctx, hipStreamSynchronize(st));
-        nb = ctx->pinned_count[0];
-      }
     }
     ICA_HIP(ctx, hipGetLastError());
   }
@@ -582,6 +608,7 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
     std::vector<int> hist((size_t)ns * std::max(1, max_iter));
     ICA_HIP(ctx, hipMemcpyAsync(hist.data(), ctx->count_hist.ptr, hist.size() * sizeof(int), hipMemcpyDeviceToHost, st));
     ICA_HIP(ctx, hipStreamSynchronize(st));
+    ctx->board_dirty = false;
     for (int s = 0; s < ns; ++s) {
       int64_t units = 0;
       for (int it = 0; it < max_iter; ++it) units += hist[(size_t)s * max_iter + it];

@@ -33,6 +33,7 @@ struct LevelArgs {
   const int* act_list;      // current active pairs (nullptr: pair index = slot)
   const int* act_count;
   int n_pairs;              // pairs covered by this launch (bound when act_list == nullptr)
+  int* host_slot;           // nullable, host-visible: receives *act_count (pairs entering this iteration)
   double* partials;         // [slot][tiles][kAccStride]; slot = index into the active list (= pair without a list)
 };
 
@@ -139,6 +140,8 @@ __global__ __launch_bounds__(kBlock) void ica_accumulate_kernel(LevelArgs a) {
 
   int pair = blockIdx.y;
   if (a.act_list) {
+    if (a.host_slot && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+      __hip_atomic_store(a.host_slot, *a.act_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if ((int)blockIdx.y >= *a.act_count) return;
     pair = a.act_list[blockIdx.y];
   }
