@@ -28,8 +28,11 @@
 #ifndef ICA_NBUF
 #define ICA_NBUF 2
 #endif
+#ifndef ICA_CH
+#define ICA_CH 16
+#endif
 #ifndef ICA_R2
-#define ICA_R2 25
+#define ICA_R2 (ICA_CH + 9)
 #endif
 
 #include "ica_kernels.hpp"
@@ -78,7 +81,7 @@ template <int TT> struct MomLayout {
 };
 
 template <int C> struct TileCfg {
-  static constexpr int ch = 16;                        // image rows per chunk: 4 waves x 4 rows
+  static constexpr int ch = ICA_CH;                    // image rows per chunk: 4 waves x ch/4 rows
   static constexpr int rw = ch / kWaves;
   static constexpr int p2 = 80, r2 = ICA_R2;               // I2 footprint buffer: pitch (floats) x rows
   static constexpr int p1 = 72, r1 = ch + 2;           // I1 buffer: columns x_t0-4 .. x_t0+67, rows yc0-1 .. yc0+ch
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(kBlock) void ica_accumulate2_kernel(LevelArgs a) {
   const bool col_ok = (x < W) & !(frame_on & ((x < a.delta) | (x >= W - a.delta)));
   const float cmx = ((x >= 1) & (x <= W - 2)) ? 1.0f : 0.0f;  // ref :81: the 1-px border keeps a zero x-derivative
   const float cx = fmaf(A[0], xf, A[2]), cy = fmaf(A[3], xf, A[5]), gxc = A[6] * xf;
-  const float vx_lo = (float)(1 - x), vx_hi = (float)(W - 3 - x);
+  const float vx_lo = (float)(1 - x), vx_hi = (float)(W - 3 - x), vy_hi = (float)(H - 3);
   const bool w4 = (W & 3) == 0;                         // rows are 16-byte aligned -> 16-B LDS-DMA
 
   // ---- plan: lane c computes the I2 footprint of chunk c (bit 30 = stage through LDS, bit 29 = skip) ----
@@ -410,14 +413,16 @@ __global__ __launch_bounds__(kBlock) void ica_accumulate2_kernel(LevelArgs a) {
         const float flx = floorf(dxw), fly = floorf(dyw);
         // 4x4 footprint inside the image (bicubic_interpolation.py:199, cval=nan); float compares, so a NaN or
         // infinite position is simply "outside"
-        const bool valid = live & (flx >= vx_lo) & (flx <= vx_hi) & (fly >= (float)(1 - y)) & (fly <= (float)(H - 3 - y));
+        const float y0f = yf + fly;  // exact: both are integers far below 2^24
+        const bool valid = live & (flx >= vx_lo) & (flx <= vx_hi) & (y0f >= 1.0f) & (y0f <= vy_hi);
         const int x0 = x + (int)flx, y0 = y + (int)fly;
         float wx[4], wy[4];
         keys_weights(dxw - flx, wx);
         keys_weights(dyw - fly, wy);
         float iw[C];
         if constexpr (STAGED) {
-          const int aoff = valid ? __mul24(y0 - 1 - y_lo, P2) + (x0 - 1 - x_lo) : 0;
+          const int aoff_raw = __mul24(y0 - 1 - y_lo, P2) + (x0 - 1 - x_lo);
+          const int aoff = valid ? aoff_raw : 0;
           const float* t = b2 + aoff;
 #pragma unroll
           for (int c = 0; c < C; ++c) {
@@ -455,7 +460,7 @@ __global__ __launch_bounds__(kBlock) void ica_accumulate2_kernel(LevelArgs a) {
         }
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-          const float d = fminf(fmaxf(iw[c], lo), hi) - mid[c];          // clip (skimage warp), ref :114
+          const float d = __builtin_amdgcn_fmed3f(iw[c], lo, hi) - mid[c];  // clip (skimage warp), ref :114
           di[c] = (valid & (fabsf(d) <= 3.0e38f)) ? d : 0.0f;           // NaN / outside -> 0 (io.py:99)
         }
       }
