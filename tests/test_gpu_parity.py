@@ -103,6 +103,39 @@ def test_normal_equations(eng, t, r, C):
         assert np.all(Hm[i, n:, :] == 0) and np.all(bv[i, n:] == 0)
 
 
+# (generic, non-round parameter values: with "nice" decimals many sampling positions fall exactly on integers,
+#  where floor() -- hence which pixels have their footprint inside the image -- is decided by the last bit)
+@pytest.mark.parametrize("t,p", [(oc.EUCLIDEAN, [3.1371, -20.2113, 0.5031]), (oc.SIMILARITY, [5.0731, 4.1177, 0.4519, 0.1033]),
+                                 (oc.AFFINITY, [-6.0317, 2.0911, 0.0513, 0.3019, -0.2531, 0.0217]),
+                                 (oc.HOMOGRAPHY, [0.2011, 0.1013, 4.0331, -0.1017, 0.1507, -3.0119, 6.1e-4, -4.3e-4]),
+                                 (oc.TRANSLATION, [300.37, 10.21])])
+@pytest.mark.parametrize("r", [oc.QUADRATIC, oc.CHARBONNIER])
+def test_normal_equations_large_warp_fallback(eng, t, p, r):
+    """Warps whose chunk footprint does not fit the LDS buffer take the direct-gather branch (some or all chunks);
+    a footprint entirely outside the image leaves every pixel invalid.  Same arithmetic, same results."""
+    C, H_, W_ = 1, 160, 200
+    I1s, I2s, _ = pairs(oc.AFFINITY, 2, H=H_, W=W_, C=C, clutter=(r != 0), seed0=777)
+    n = oc.nparams(t)
+    prob = eng.problem(2, H_, W_, C, t, r, delta=5)
+    pp = np.zeros((2, 8))
+    pp[0, :n] = p
+    pp[1, :n] = np.array(p) * 0.5
+    lam = 25.0
+    Hm, bv = eng.normal_equations(to_dev(eng, *I1s), to_dev(eng, *I2s), torch.from_numpy(pp), prob, lambda_it=lam)
+    Hm, bv = Hm.cpu().numpy(), bv.cpu().numpy()
+    for i in range(2):
+        I1, I2 = I1s[i].astype(np.float64), I2s[i].astype(np.float64)
+        Ix, Iy = oc.gradient(I1, True, 5)
+        DIJ = oc.steepest_descent_images(Ix, Iy, oc.jacobian(t, W_, H_), n)
+        DI = oc.warp_params(I2, pp[i, :n], t) - I1
+        rho = oc.robust_error_function(DI, lam, r) if r else None
+        Hw, bw = oc.hessian(DIJ, rho), oc.independent_vector(DIJ, DI, rho)
+        sc = np.sqrt(np.diag(Hw))
+        np.testing.assert_allclose(Hm[i, :n, :n] / np.outer(sc, sc), Hw / np.outer(sc, sc), atol=2e-6)
+        bscale = sc * max(np.sqrt(np.nansum((DI * (np.sqrt(rho)[..., None] if r else 1.0)) ** 2)), 1.0)
+        np.testing.assert_allclose(bv[i, :n] / bscale, bw / bscale, atol=5e-6)
+
+
 @pytest.mark.parametrize("t", TYPES)
 def test_solve_update_operator(eng, t):
     rng = np.random.default_rng(t)
