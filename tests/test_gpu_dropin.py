@@ -66,3 +66,36 @@ def test_uint8_input_is_cast_like_the_reference():
                                         False)
     b = inverse_compositional_algorithm(I1, I2, np.zeros(2), T.TRANSLATION, 1e-3, True, 5, False)
     np.testing.assert_array_equal(a[0], b[0])
+
+
+def test_host_pointer_entry_point_matches_device_entry_point():
+    """ica_solve_batch (host pointers, copies inside) == ica_solve_batch_dev on the same data."""
+    import ctypes as C
+    import torch
+    from inverse_compositional_algorithm_amd import _lib
+    from inverse_compositional_algorithm_amd.engine import IcaEngine
+    eng = IcaEngine(0)
+    t, B, H, W, Cn = oc.AFFINITY, 2, 96, 128, 3
+    prs = [syn.make_pair(900 + i, H, W, Cn, t) for i in range(B)]
+    i1 = np.ascontiguousarray(np.stack([np.moveaxis(p[0], 2, 0) for p in prs]))
+    i2 = np.ascontiguousarray(np.stack([np.moveaxis(p[1], 2, 0) for p in prs]))
+    prob = eng.problem(B, H, W, Cn, t, 0, nscales=2, delta=5)
+    p = np.zeros((B, 8))
+    err = np.zeros(B)
+    nit = np.zeros((B, 2), np.int32)
+    di, iw = np.empty_like(i1), np.empty_like(i1)
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+    _lib.check(eng.lib.ica_solve_batch(eng.ctx, C.byref(prob), ptr(i1), ptr(i2), ptr(p), ptr(err), ptr(nit), ptr(di), ptr(iw),
+                                        None, None), eng.ctx)
+    ref = eng.solve(torch.from_numpy(i1).to(eng.device), torch.from_numpy(i2).to(eng.device), prob, want_images=True)
+    np.testing.assert_array_equal(p, ref.p.cpu().numpy())
+    np.testing.assert_array_equal(nit, ref.niter.cpu().numpy())
+    np.testing.assert_array_equal(np.isnan(iw), np.isnan(ref.Iw.cpu().numpy()))
+    np.testing.assert_array_equal(np.nan_to_num(di), np.nan_to_num(ref.DI.cpu().numpy()))
+    # argument errors come back as status codes carrying the reference's messages
+    bad = eng.problem(B, H, W, Cn, t, 0, tol=0.01)
+    assert eng.lib.ica_solve_batch(eng.ctx, C.byref(bad), ptr(i1), ptr(i2), ptr(p), ptr(err), ptr(nit), None, None, None,
+                                   None) == -3
+    bad = eng.problem(B, H, W, 2, t, 0)
+    assert eng.lib.ica_solve_batch(eng.ctx, C.byref(bad), ptr(i1), ptr(i2), ptr(p), ptr(err), ptr(nit), None, None, None,
+                                   None) == -1
