@@ -118,7 +118,7 @@ __device__ __forceinline__ void displacement_col(const float* A, float cx, float
 }
 
 template <int TT, int MODE, int C>
-__global__ __launch_bounds__(kBlock) void ica_accumulate2_kernel(LevelArgs a) {
+__global__ __launch_bounds__(kBlock) void ica_accumulate2_kernel(LevelArgs a, SolveArgs sa) {
   constexpr int N = NP<TT>::n;
   constexpr int NT = N * (N + 1) / 2;
   constexpr bool kB = (MODE != kModeHessian);
@@ -583,7 +583,42 @@ __global__ __launch_bounds__(kBlock) void ica_accumulate2_kernel(LevelArgs a) {
     val += __shfl_down(val, 1, 64);
     if (q == 0 && have) {
       double* out = a.partials + ((size_t)pair_slot * ntiles + tile_id) * kAccStride;  // indexed by launch slot
-      out[e < N ? e : kMaxN + (e - N)] = val;
+      double* dst = out + (e < N ? e : kMaxN + (e - N));
+      if (kB && sa.tickets)  // fused solve: write-through (sc1) store, so no L2 write-back fence is needed below
+        __hip_atomic_store(dst, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else
+        *dst = val;
+    }
+  }
+
+  // ---- fused solve: the last tile of a pair to arrive sums the pair's partials, solves and updates p ----
+  // Placement-independent hand-off (cdna_hip_programming.md G16, counter form with write-through stores): the
+  // partials above were stored sc1 (agent-scope atomic stores), every storing wave drains them (vmcnt(0)), barrier,
+  // then lane 0 takes a ticket with a relaxed agent-scope add; the workgroup that draws the last ticket does ONE
+  // agent-scope acquire (invalidates its L1) and reads the other workgroups' partials with plain loads.
+  if constexpr (kB) {
+    if (sa.tickets) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *sa.clr_count = 0;
+        if (sa.count_hist) sa.count_hist[sa.level * sa.max_iter + sa.iter] = *sa.cur_count;
+      }
+      int* flag = reinterpret_cast<int*>(lds);  // (the fold scratch is dead after the barrier below)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const int ticket = __hip_atomic_fetch_add(sa.tickets + pair_slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (ticket == ntiles - 1);
+        if (last) {
+          __hip_atomic_store(sa.tickets + pair_slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next iteration
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        *flag = last;
+      }
+      __syncthreads();
+      const bool last = *flag != 0;
+      __syncthreads();
+      if (last) solve_pair(sa, pair_slot, pair, reinterpret_cast<double*>(lds) + 8);
     }
   }
 }

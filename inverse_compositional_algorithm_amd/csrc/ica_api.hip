@@ -69,7 +69,7 @@ struct ica_ctx {
   // workspaces
   DevBuf pyr1[ICA_MAX_SCALES], pyr2[ICA_MAX_SCALES];  // levels >= 1
   DevBuf tmp_resample;                                // intermediate of the separable pyramid pass
-  DevBuf partials, hinv, p_prev, lambda_it, error, niter, lists, counts, count_hist, minmax, mm_part, mm_in;
+  DevBuf partials, hinv, p_prev, lambda_it, error, niter, lists, counts, count_hist, minmax, mm_part, mm_in, tickets;
   DevBuf scratch_p;
   int* pinned_count = nullptr;   // 4 ints for synchronous reads + a [scales][max_iter] board the kernels post to
   int* board = nullptr;          // host pointer of the board (pinned, host-coherent)
@@ -86,7 +86,7 @@ struct ica_ctx {
     for (auto e : ev_pool) (void)hipEventDestroy(e);
     for (int i = 0; i < ICA_MAX_SCALES; ++i) { pyr1[i].release(); pyr2[i].release(); }
     DevBuf* all[] = {&tmp_resample, &partials, &hinv, &p_prev, &lambda_it, &error, &niter, &lists, &counts,
-                     &count_hist, &minmax, &mm_part, &mm_in, &scratch_p};
+                     &count_hist, &minmax, &mm_part, &mm_in, &tickets, &scratch_p};
     for (auto* b : all) b->release();
     if (pinned_count) (void)hipHostFree(pinned_count);
     if (board) (void)hipHostFree(board);
@@ -277,9 +277,12 @@ int launch_pyramid_down(ica_ctx* ctx, int batch, int C, int H, int W, int h, int
 
 // ICA_ACCUM=1 selects the simple direct-gather kernel (kept as an in-library cross-check of the LDS-staged one)
 int g_accum_variant = 2;
+int g_fuse_solve = 0;  // ICA_FUSE_SOLVE=n: fuse the per-pair solve into the iteration kernel (last-arriving tile solves)
+                      // when <= n pairs are left.  Measured slower than the separate solve kernel at every n on
+                      // configs[1] (6.41-6.55 ms vs 6.25 ms per step), so it is off by default; kept, tested, as an option.
 
 template <int TT, int MODE>
-void launch_accumulate_c(int C, dim3 grid, hipStream_t st, const LevelArgs& a) {
+void launch_accumulate_c(int C, dim3 grid, hipStream_t st, const LevelArgs& a, const SolveArgs& sa) {
   if (g_accum_variant == 1) {
     if (C == 1)
       hipLaunchKernelGGL((ica_accumulate_kernel<TT, MODE, 1>), grid, dim3(kBlock), 0, st, a);
@@ -289,27 +292,29 @@ void launch_accumulate_c(int C, dim3 grid, hipStream_t st, const LevelArgs& a) {
     // 1-D grid: (pairs rounded up to a multiple of 8) x tiles, decoded XCD-aware inside the kernel
     const dim3 g1((unsigned)(((grid.y + 7) / 8) * 8 * grid.x));
     if (C == 1)
-      hipLaunchKernelGGL((ica_accumulate2_kernel<TT, MODE, 1>), g1, dim3(kBlock), 0, st, a);
+      hipLaunchKernelGGL((ica_accumulate2_kernel<TT, MODE, 1>), g1, dim3(kBlock), 0, st, a, sa);
     else
-      hipLaunchKernelGGL((ica_accumulate2_kernel<TT, MODE, 3>), g1, dim3(kBlock), 0, st, a);
+      hipLaunchKernelGGL((ica_accumulate2_kernel<TT, MODE, 3>), g1, dim3(kBlock), 0, st, a, sa);
   }
 }
 
 template <int MODE>
-void launch_accumulate(int tt, int C, dim3 grid, hipStream_t st, const LevelArgs& a) {
+void launch_accumulate(int tt, int C, dim3 grid, hipStream_t st, const LevelArgs& a, const SolveArgs& sa) {
   switch (tt) {
-    case ICA_TRANSLATION: launch_accumulate_c<ICA_TRANSLATION, MODE>(C, grid, st, a); break;
-    case ICA_EUCLIDEAN: launch_accumulate_c<ICA_EUCLIDEAN, MODE>(C, grid, st, a); break;
-    case ICA_SIMILARITY: launch_accumulate_c<ICA_SIMILARITY, MODE>(C, grid, st, a); break;
-    case ICA_AFFINITY: launch_accumulate_c<ICA_AFFINITY, MODE>(C, grid, st, a); break;
-    default: launch_accumulate_c<ICA_HOMOGRAPHY, MODE>(C, grid, st, a); break;
+    case ICA_TRANSLATION: launch_accumulate_c<ICA_TRANSLATION, MODE>(C, grid, st, a, sa); break;
+    case ICA_EUCLIDEAN: launch_accumulate_c<ICA_EUCLIDEAN, MODE>(C, grid, st, a, sa); break;
+    case ICA_SIMILARITY: launch_accumulate_c<ICA_SIMILARITY, MODE>(C, grid, st, a, sa); break;
+    case ICA_AFFINITY: launch_accumulate_c<ICA_AFFINITY, MODE>(C, grid, st, a, sa); break;
+    default: launch_accumulate_c<ICA_HOMOGRAPHY, MODE>(C, grid, st, a, sa); break;
   }
 }
 
-void launch_accumulate_mode(int mode, int tt, int C, dim3 grid, hipStream_t st, const LevelArgs& a) {
-  if (mode == kModeL2) launch_accumulate<kModeL2>(tt, C, grid, st, a);
-  else if (mode == kModeRobust) launch_accumulate<kModeRobust>(tt, C, grid, st, a);
-  else launch_accumulate<kModeHessian>(tt, C, grid, st, a);
+// `sa.tickets != nullptr` makes the last-arriving tile of each pair run the solve inside the same launch
+void launch_accumulate_mode(int mode, int tt, int C, dim3 grid, hipStream_t st, const LevelArgs& a,
+                            const SolveArgs& sa = SolveArgs{}) {
+  if (mode == kModeL2) launch_accumulate<kModeL2>(tt, C, grid, st, a, sa);
+  else if (mode == kModeRobust) launch_accumulate<kModeRobust>(tt, C, grid, st, a, sa);
+  else launch_accumulate<kModeHessian>(tt, C, grid, st, a, sa);
 }
 
 int launch_warp(ica_ctx* ctx, int batch, int C, int H, int W, int tt, const float* I2, const double* p,
@@ -350,6 +355,7 @@ int ensure_state(ica_ctx* ctx, const ica_problem* pr, const LevelGeom* g) {
   ICA_HIP(ctx, ctx->niter.ensure(B * sizeof(int)));
   ICA_HIP(ctx, ctx->lists.ensure(3 * B * sizeof(int)));
   ICA_HIP(ctx, ctx->counts.ensure(4 * sizeof(int)));
+  ICA_HIP(ctx, ctx->tickets.ensure(B * sizeof(int)));
   ICA_HIP(ctx, ctx->count_hist.ensure((size_t)pr->nscales * std::max(1, pr->max_iter) * sizeof(int)));
   ICA_HIP(ctx, ctx->minmax.ensure((size_t)pr->nscales * B * 2 * sizeof(float)));
   ICA_HIP(ctx, ctx->mm_in.ensure(B * 2 * sizeof(float)));
@@ -414,6 +420,7 @@ int ica_create(int device, ica_ctx** out) {
   c->device = device;
   if (const char* e = getenv("ICA_POLL_EVERY")) c->poll_every = std::max(1, atoi(e));
   if (const char* e = getenv("ICA_ACCUM")) g_accum_variant = (atoi(e) == 1) ? 1 : 2;
+  if (const char* e = getenv("ICA_FUSE_SOLVE")) g_fuse_solve = atoi(e);
   *out = c;
   return ICA_OK;
 }
@@ -502,6 +509,7 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
   if (trace_out)
     ICA_HIP(ctx, hipMemsetAsync(trace_out, 0, (size_t)B * ns * max_iter * ICA_TRACE_STRIDE * sizeof(double), st));
   ICA_HIP(ctx, hipMemsetAsync(niter_out, 0, (size_t)B * ns * sizeof(int32_t), st));
+  ICA_HIP(ctx, hipMemsetAsync(ctx->tickets.ptr, 0, (size_t)B * sizeof(int), st));
 
   int* lists = ctx->lists.as<int>();
   int* counts = ctx->counts.as<int>();
@@ -573,13 +581,6 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
         ICA_TRY(next_event(&e0));
         ICA_HIP(ctx, hipEventRecord(ctx->ev_pool[e0], st));
       }
-      launch_accumulate_mode(robust ? kModeRobust : kModeL2, tt, C, dim3(lg.tiles, nb), st, la);
-      if (ctx->profiling && s == 0) {
-        ICA_TRY(next_event(&e1));
-        ICA_HIP(ctx, hipEventRecord(ctx->ev_pool[e1], st));
-        evrecs.push_back({s, e0, e1});
-      }
-      launches[s]++;
       SolveArgs sa{};
       sa.tt = tt; sa.n = n; sa.robust = robust; sa.flags = pr->flags; sa.tiles = lg.tiles; sa.max_iter = max_iter;
       sa.level = s; sa.nscales = ns; sa.iter = it; sa.tol = pr->tol; sa.lambda_user = pr->lambda;
@@ -589,7 +590,16 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
       sa.cur_list = lists + (size_t)cur * B; sa.cur_count = counts + cur;
       sa.nxt_list = lists + (size_t)nxt * B; sa.nxt_count = counts + nxt; sa.clr_count = counts + clr;
       sa.count_hist = ctx->count_hist.as<int>(); sa.trace = trace_out;
-      hipLaunchKernelGGL(ica_solve_kernel, dim3(nb), dim3(kSolveThreads), 0, st, sa);
+      const bool fuse = nb <= g_fuse_solve && g_accum_variant == 2;
+      sa.tickets = fuse ? ctx->tickets.as<int>() : nullptr;
+      launch_accumulate_mode(robust ? kModeRobust : kModeL2, tt, C, dim3(lg.tiles, nb), st, la, sa);
+      if (ctx->profiling && s == 0) {
+        ICA_TRY(next_event(&e1));
+        ICA_HIP(ctx, hipEventRecord(ctx->ev_pool[e1], st));
+        evrecs.push_back({s, e0, e1});
+      }
+      launches[s]++;
+      if (!fuse) hipLaunchKernelGGL(ica_solve_kernel, dim3(nb), dim3(kSolveThreads), 0, st, sa);
     }
     ICA_HIP(ctx, hipGetLastError());
   }

@@ -300,15 +300,16 @@ struct SolveArgs {
   int* clr_count;
   int* count_hist;        // [nscales][max_iter]
   double* trace;          // nullable [B][nscales][max_iter][10]
+  int* tickets;           // [B] arrival counters of the fused (last-tile-solves) mode; nullptr: separate solve kernel
 };
 
 // Sum the tile partials of one launch slot in a fixed order (deterministic): 256 threads = 4 groups x 64 lanes;
 // lane k < 44 of group g adds tiles g, g+4, g+8, ... of accumulator k (4 loads in flight), then the 4 group sums are
 // added in group order.  Only accumulators [k_lo, k_hi) are touched.
 constexpr int kSolveThreads = 256;
+constexpr int kSolveScratch = 5 * kAccStride + 2 * kMaxN * kMaxN + kLuWork;  // doubles of LDS a solve needs
 __device__ __forceinline__ void gather_partials(const double* partials, int slot, int tiles, double* s /*LDS[44]*/,
-                                                int k_lo = 0, int k_hi = kAccStride) {
-  __shared__ double part[4][kAccStride];
+                                                double* part /*LDS[4][44]*/, int k_lo = 0, int k_hi = kAccStride) {
   const int k = threadIdx.x & 63, g = threadIdx.x >> 6;
   if (k >= k_lo && k < k_hi) {
     const double* q = partials + (size_t)slot * tiles * kAccStride + k;
@@ -321,22 +322,26 @@ __device__ __forceinline__ void gather_partials(const double* partials, int slot
       a3 += q[(size_t)(t + 12) * kAccStride];
     }
     for (; t < tiles; t += 4) a0 += q[(size_t)t * kAccStride];
-    part[g][k] = (a0 + a1) + (a2 + a3);
+    part[g * kAccStride + k] = (a0 + a1) + (a2 + a3);
   }
   __syncthreads();
   if (threadIdx.x < kAccStride) {
     const int kk = threadIdx.x;
-    s[kk] = (kk >= k_lo && kk < k_hi) ? ((part[0][kk] + part[1][kk]) + part[2][kk]) + part[3][kk] : 0.0;
+    s[kk] = (kk >= k_lo && kk < k_hi)
+                ? ((part[kk] + part[kAccStride + kk]) + part[2 * kAccStride + kk]) + part[3 * kAccStride + kk]
+                : 0.0;
   }
   __syncthreads();
 }
 
 // L2 setup: H^-1 once per level (ref :102-103).
 __global__ __launch_bounds__(kSolveThreads) void ica_setup_solve_kernel(const double* partials, int tiles, int n, double* Hinv) {
-  __shared__ double s[kAccStride];
+  __shared__ double scratch[kSolveScratch];
+  double* s = scratch;
+  double* Hm = scratch + 5 * kAccStride;
+  double* ws = Hm + 2 * kMaxN * kMaxN;
   const int pair = blockIdx.x;
-  gather_partials(partials, pair, tiles, s, kMaxN, kAccStride);
-  __shared__ double Hm[kMaxN * kMaxN], ws[kLuWork];
+  gather_partials(partials, pair, tiles, s, scratch + kAccStride, kMaxN, kAccStride);
   if (threadIdx.x == 0) {
     for (int k = 0; k < n; ++k)
       for (int m = k; m < n; ++m) Hm[k * kMaxN + m] = Hm[m * kMaxN + k] = s[kMaxN + tri_index(k, m, n)];
@@ -344,17 +349,14 @@ __global__ __launch_bounds__(kSolveThreads) void ica_setup_solve_kernel(const do
   }
 }
 
-// Solve + compositional update + loop control for one active pair (ref :117-131 / :233-259).
-__global__ __launch_bounds__(kSolveThreads) void ica_solve_kernel(SolveArgs a) {
-  __shared__ double s[kAccStride];
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    *a.clr_count = 0;
-    if (a.count_hist) a.count_hist[a.level * a.max_iter + a.iter] = *a.cur_count;
-  }
-  if ((int)blockIdx.x >= *a.cur_count) return;
-  const int pair = a.cur_list[blockIdx.x];
-  gather_partials(a.partials, blockIdx.x, a.tiles, s, 0, a.robust ? kAccStride : kMaxN);  // indexed by launch slot
-  __shared__ double Hm[kMaxN * kMaxN], Hi[kMaxN * kMaxN], ws[kLuWork];
+// Solve + compositional update + loop control for one active pair (ref :117-131 / :233-259).  Called by all 256
+// threads of a workgroup; `scratch` is kSolveScratch doubles of LDS.  `slot` indexes the launch's partials.
+__device__ __forceinline__ void solve_pair(const SolveArgs& a, int slot, int pair, double* scratch) {
+  double* s = scratch;
+  double* Hm = scratch + 5 * kAccStride;
+  double* Hi = Hm + kMaxN * kMaxN;
+  double* ws = Hi + kMaxN * kMaxN;
+  gather_partials(a.partials, slot, a.tiles, s, scratch + kAccStride, 0, a.robust ? kAccStride : kMaxN);
   if (threadIdx.x != 0) return;
   const int n = a.n;
   const double* hinv = a.Hinv + (size_t)pair * 64;
@@ -395,6 +397,16 @@ __global__ __launch_bounds__(kSolveThreads) void ica_solve_kernel(SolveArgs a) {
     const int idx = atomicAdd(a.nxt_count, 1);
     a.nxt_list[idx] = pair;
   }
+}
+
+__global__ __launch_bounds__(kSolveThreads) void ica_solve_kernel(SolveArgs a) {
+  __shared__ double scratch[kSolveScratch];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    *a.clr_count = 0;
+    if (a.count_hist) a.count_hist[a.level * a.max_iter + a.iter] = *a.cur_count;
+  }
+  if ((int)blockIdx.x >= *a.cur_count) return;
+  solve_pair(a, blockIdx.x, a.cur_list[blockIdx.x], scratch);
 }
 
 struct LevelInitArgs {
@@ -515,9 +527,9 @@ __global__ void ica_minmax_final_kernel(const float* __restrict__ part, int chun
 __global__ void ica_gather_normal_equations_kernel(const double* partials, int tiles, int n, int batch, int have_b,
                                                    int have_h, const double* Hsetup_partials, double* Hout,
                                                    double* bout) {
-  __shared__ double s[kAccStride];
+  __shared__ double s[kAccStride], part[4 * kAccStride];
   const int pair = blockIdx.x;
-  gather_partials(partials, pair, tiles, s);
+  gather_partials(partials, pair, tiles, s, part);
   if (threadIdx.x == 0) {
     for (int i = 0; i < 8; ++i) bout[(size_t)pair * 8 + i] = (have_b && i < n) ? s[i] : 0.0;
     if (have_h) {

@@ -248,3 +248,25 @@ def test_deterministic(eng):
     prob = eng.problem(4, 128, 160, 3, t, oc.LORENTZIAN, nscales=2)
     a, b = eng.solve(d1, d2, prob), eng.solve(d1, d2, prob)
     assert torch.equal(a.p, b.p) and torch.equal(a.niter, b.niter)
+
+
+def test_fused_solve_option_gives_the_same_iterates(eng, monkeypatch):
+    """ICA_FUSE_SOLVE (last-arriving tile runs the solve inside the iteration kernel) is an alternative schedule of the
+    same arithmetic: identical iteration counts and parameters equal to rounding."""
+    import os
+    import subprocess
+    import sys
+    code = ("import numpy as np, torch, sys; sys.path.insert(0, %r);"
+            "from inverse_compositional_algorithm_amd.engine import IcaEngine;"
+            "e = IcaEngine(0); I1, I2, _ = e.make_batch(5, 16, 128, 160, 1, 5, robust_clutter=True);"
+            "r = e.solve(I1, I2, e.problem(16, 128, 160, 1, 5, 3, nscales=2, delta=5));"
+            "np.save(sys.argv[1], np.concatenate([r.p.cpu().numpy().ravel(), r.niter.cpu().numpy().ravel()]))"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    outs = []
+    for fuse in ("0", "1000"):
+        path = f"/tmp/ica_fuse_{fuse}.npy"
+        env = dict(os.environ, ICA_FUSE_SOLVE=fuse)
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=300)
+        outs.append(np.load(path))
+    np.testing.assert_array_equal(outs[0][-32:], outs[1][-32:])          # iteration counts
+    np.testing.assert_allclose(outs[0][:-32], outs[1][:-32], rtol=1e-9, atol=1e-12)
