@@ -658,11 +658,31 @@ __global__ __launch_bounds__(kBlock) void ica_resample_h_kernel(const float* __r
   const int span = op.start[o_last] + op.K - c0;  // <= span_pad
   const int half = (span_pad + 1) >> 1;
   const float* src = in + (size_t)pl * H * op.n_in;
-  for (int r = threadIdx.x >> 6; r < kRowsH; r += kWaves) {
-    const int y = r_base + r;
-    for (int c = threadIdx.x & 63; c < span; c += 64) {
-      const int xg = c0 + c;
-      tile[r * span_pad + (c & 1) * half + (c >> 1)] = (y < H && xg < op.n_in) ? src[(size_t)y * op.n_in + xg] : 0.0f;
+  {
+    // staging: 8 rows x up to 4 column segments per wave are read into registers first (all loads in flight
+    // together), then written to LDS
+    const int lane_c = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr int kSeg = 3;  // 64-column segments per row kept in flight (span <= 192 in one go; wider spans loop)
+    for (int cs = 0; cs < span; cs += 64 * kSeg) {
+      float v[kRowsH / kWaves][kSeg];
+#pragma unroll
+      for (int i = 0; i < kRowsH / kWaves; ++i) {
+        const int y = r_base + wv + i * kWaves;
+#pragma unroll
+        for (int j = 0; j < kSeg; ++j) {
+          const int c = cs + j * 64 + lane_c, xg = c0 + c;
+          v[i][j] = (c < span && y < H && xg < op.n_in) ? src[(size_t)y * op.n_in + xg] : 0.0f;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < kRowsH / kWaves; ++i) {
+        const int r = wv + i * kWaves;
+#pragma unroll
+        for (int j = 0; j < kSeg; ++j) {
+          const int c = cs + j * 64 + lane_c;
+          if (c < span) tile[r * span_pad + (c & 1) * half + (c >> 1)] = v[i][j];
+        }
+      }
     }
   }
   __syncthreads();
