@@ -180,6 +180,13 @@ int ica_op_pyramid_down_dev(ica_ctx* ctx, int batch, int channels, int height, i
 int ica_op_zoom_in_parameters_dev(ica_ctx* ctx, int batch, int transform_type, int w, int h, int ww,
                                   int hh, double* p_inout);
 
+/* transformation.py:266-318 transform_image (the reference's test-data generator): out = bilinear I(M.x) with
+ * skimage.transform.warp(image, tform.inverse, preserve_range=True) semantics (order 1, mode constant, cval 0: a tap
+ * outside the image contributes 0; clipped to the input range).  M is [B][9], row-major 3x3, the matrix that maps
+ * OUTPUT pixel (col,row,1) to the INPUT position, i.e. inv(params2matrix(gt)) as the reference passes tform.inverse. */
+int ica_op_transform_image_dev(ica_ctx* ctx, int batch, int channels, int height, int width, const float* I,
+                               const double* M, float* out);
+
 #ifdef __cplusplus
 }
 #endif

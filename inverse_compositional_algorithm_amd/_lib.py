@@ -56,6 +56,7 @@ _SIGNATURES = {
     "ica_op_solve_update_dev": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "ica_op_pyramid_down_dev": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _P, _P]),
     "ica_op_zoom_in_parameters_dev": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "ica_op_transform_image_dev": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

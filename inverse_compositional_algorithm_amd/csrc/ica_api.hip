@@ -773,4 +773,26 @@ int ica_op_zoom_in_parameters_dev(ica_ctx* ctx, int batch, int tt, int w, int h,
   return ICA_OK;
 }
 
+int ica_op_transform_image_dev(ica_ctx* ctx, int batch, int channels, int height, int width, const float* I,
+                               const double* M, float* out) {
+  if (!ctx || !I || !M || !out || batch <= 0 || height <= 0 || width <= 0) return ICA_EINVAL_ARG;
+  if (channels != 1 && channels != 3) return ICA_EINVAL_SHAPE;
+  ICA_HIP(ctx, hipSetDevice(ctx->device));
+  ICA_HIP(ctx, ctx->mm_in.ensure((size_t)batch * 2 * sizeof(float)));
+  ICA_TRY(launch_minmax(ctx, batch, (size_t)channels * height * width, I, ctx->mm_in.as<float>()));
+  for (int b0 = 0; b0 < batch; b0 += 32768) {
+    const int nb = std::min(32768, batch - b0);
+    const size_t off = (size_t)b0 * channels * height * width;
+    dim3 grid((width + 63) / 64, (height + kWaves - 1) / kWaves, nb);
+    if (channels == 1)
+      hipLaunchKernelGGL(ica_transform_image_kernel<1>, grid, dim3(kBlock), 0, ctx->stream, I + off, height, width,
+                         M + (size_t)b0 * 9, ctx->mm_in.as<float>() + (size_t)b0 * 2, out + off);
+    else
+      hipLaunchKernelGGL(ica_transform_image_kernel<3>, grid, dim3(kBlock), 0, ctx->stream, I + off, height, width,
+                         M + (size_t)b0 * 9, ctx->mm_in.as<float>() + (size_t)b0 * 2, out + off);
+  }
+  ICA_HIP(ctx, hipGetLastError());
+  return ICA_OK;
+}
+
 }  // extern "C"

@@ -483,6 +483,37 @@ __global__ __launch_bounds__(kBlock) void ica_warp_kernel(const float* __restric
   }
 }
 
+// ---- transform_image (transformation.py:266-318): bilinear resampling under a 3x3 matrix, cval 0, clipped ----
+template <int C>
+__global__ __launch_bounds__(kBlock) void ica_transform_image_kernel(const float* __restrict__ I, int H, int W,
+                                                                     const double* __restrict__ M,
+                                                                     const float* __restrict__ minmax,
+                                                                     float* __restrict__ out) {
+  const int pair = blockIdx.z;
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * kWaves + (threadIdx.x >> 6);
+  if (x >= W || y >= H) return;
+  const double* m = M + (size_t)pair * 9;
+  // test-data generation, not the hot path: positions in fp64 like skimage
+  const double w = m[6] * x + m[7] * y + m[8];
+  const double xs = (m[0] * x + m[1] * y + m[2]) / w, ys = (m[3] * x + m[4] * y + m[5]) / w;
+  const double x0 = floor(xs), y0 = floor(ys), x1 = ceil(xs), y1 = ceil(ys);
+  const float dx = (float)(xs - x0), dy = (float)(ys - y0);
+  const size_t plane = (size_t)H * W;
+  const float lo = minmax[pair * 2], hi = minmax[pair * 2 + 1];
+  auto px = [&](const float* q, double r, double c) -> float {
+    return (r >= 0 && r < H && c >= 0 && c < W) ? q[(size_t)r * W + (size_t)c] : 0.0f;
+  };
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const float* q = I + ((size_t)pair * C + c) * plane;
+    const float top = (1.0f - dx) * px(q, y0, x0) + dx * px(q, y0, x1);
+    const float bot = (1.0f - dx) * px(q, y1, x0) + dx * px(q, y1, x1);
+    const float v = (1.0f - dy) * top + dy * bot;
+    out[((size_t)pair * C + c) * plane + (size_t)y * W + x] = fminf(fmaxf(v, lo), hi);
+  }
+}
+
 // ---- min / max of each image ----------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void ica_minmax_partial_kernel(const float* __restrict__ img, size_t elems,
                                                                     int chunks, float* __restrict__ part) {

@@ -190,6 +190,17 @@ class IcaEngine:
         check(self.lib.ica_op_zoom_in_parameters_dev(self.ctx, B, int(transform_type), w, h, ww, hh, _ptr(p)), self.ctx)
         return p
 
+    def transform_image(self, I: torch.Tensor, M) -> torch.Tensor:
+        """Bilinear resampling out(x) = I(M x) (cval 0, clipped), M [B,3,3] float64 (transformation.py:316)."""
+        self._images(I)
+        B, Cc, H, W = I.shape
+        M = torch.as_tensor(M, dtype=torch.float64, device=self.device).reshape(-1, 9)
+        M = (M / M[:, 8:9]).expand(B, 9).contiguous()
+        out = torch.empty_like(I)
+        self._bind_stream()
+        check(self.lib.ica_op_transform_image_dev(self.ctx, B, Cc, H, W, _ptr(I), _ptr(M), _ptr(out)), self.ctx)
+        return out
+
     def _params(self, p, B):
         p = torch.as_tensor(p, dtype=torch.float64, device=self.device)
         if p.dim() == 1:

@@ -96,3 +96,30 @@ def update_transform(p: np.ndarray, dp: np.ndarray, transform_type, exact: bool 
             if not exact:
                 p[4] -= (-a + c * g) / det
     return p
+
+
+def transform_image(image, transformation_type, gt):
+    """Test-data generator of the reference (transformation.py:266-318): bilinear warp of `image` by the inverse of
+    the transform `gt`, zeros outside, float64 (H, W, C) result.  Runs on the GPU (ica_op_transform_image_dev)."""
+    import torch
+
+    from .inverse_compositional_algorithm import _engine
+    image = np.asarray(image)
+    if image.dtype != np.float64:
+        image = image.astype(np.float64)
+        print("Image type: ", image.dtype)                              # the reference prints these two lines
+        print("Range of image: ", np.min(image), np.max(image))
+    t = _tt(transformation_type)
+    gt = np.asarray(gt, dtype=np.float64)
+    if np.all(np.abs(gt) < 1e-10):
+        M = np.eye(3)
+    elif t == 2:   # EuclideanTransform(rotation=-gt[2], translation=gt[:2])  (transformation.py:309)
+        M = params2matrix([gt[0], gt[1], -gt[2]], 2)
+    elif t == 1:   # EuclideanTransform(translation=gt)                         (transformation.py:305)
+        M = params2matrix(gt, 1)
+    else:
+        M = params2matrix(gt, t)
+    eng = _engine()
+    x = np.ascontiguousarray(np.moveaxis(image.astype(np.float32), 2, 0))[None]
+    out = eng.transform_image(torch.from_numpy(x).to(eng.device), np.linalg.inv(M)[None])
+    return np.moveaxis(out[0].cpu().numpy().astype(np.float64), 0, 2)

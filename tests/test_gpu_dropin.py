@@ -99,3 +99,33 @@ def test_host_pointer_entry_point_matches_device_entry_point():
     bad = eng.problem(B, H, W, 2, t, 0)
     assert eng.lib.ica_solve_batch(eng.ctx, C.byref(bad), ptr(i1), ptr(i2), ptr(p), ptr(err), ptr(nit), None, None, None,
                                    None) == -1
+
+
+@pytest.mark.parametrize("t,gt", [(T.TRANSLATION, [10, 5]), (T.EUCLIDEAN, [10., 5., -0.1]), (T.SIMILARITY, [0., 0., -0.1, 0.]),
+                                  (T.AFFINITY, [3.3, -2.1, 0.04, 0.02, -0.03, 0.05]),
+                                  (T.HOMOGRAPHY, [0.02, 0.01, 4.0, -0.01, 0.03, -2.0, 2e-5, -1e-5])])
+def test_transform_image_matches_bilinear_restatement(t, gt):
+    """transformation.transform_image (ref :266-318) = skimage warp(image, tform.inverse), order 1, cval 0."""
+    from inverse_compositional_algorithm_amd import transformation as tr
+    I2 = _pair(oc.AFFINITY, seed=77, H=96, W=128)[1]
+    got = tr.transform_image(I2, t, gt)
+    g = np.asarray(gt, float)
+    M = oc.params2matrix([g[0], g[1], -g[2]], 2) if t == T.EUCLIDEAN else oc.params2matrix(g, t.value)
+    Minv = np.linalg.inv(M)
+    H, W = I2.shape[:2]
+    ii, jj = np.mgrid[0:H, 0:W].astype(np.float64)
+    w = Minv[2, 0] * jj + Minv[2, 1] * ii + Minv[2, 2]
+    x = (Minv[0, 0] * jj + Minv[0, 1] * ii + Minv[0, 2]) / w
+    y = (Minv[1, 0] * jj + Minv[1, 1] * ii + Minv[1, 2]) / w
+    x0, y0, x1, y1 = np.floor(x), np.floor(y), np.ceil(x), np.ceil(y)
+    dx, dy = (x - x0)[..., None], (y - y0)[..., None]
+
+    def px(r, c):
+        ok = (r >= 0) & (r < H) & (c >= 0) & (c < W)
+        return np.where(ok[..., None], I2[np.clip(r, 0, H - 1).astype(int), np.clip(c, 0, W - 1).astype(int)], 0.0)
+    want = (1 - dy) * ((1 - dx) * px(y0, x0) + dx * px(y0, x1)) + dy * ((1 - dx) * px(y1, x0) + dx * px(y1, x1))
+    want = np.clip(want, I2.min(), I2.max())
+    assert got.shape == want.shape and got.dtype == np.float64
+    # positions that fall within 1e-9 of an integer may pick a different (equally weighted) tap pair: exclude none,
+    # the interpolant is continuous, so values still agree
+    np.testing.assert_allclose(got, want, atol=5e-3)
