@@ -253,7 +253,6 @@ __global__ __launch_bounds__(kBlock) void ica_accumulate2_kernel(LevelArgs a, So
   auto elem1 = [&](int j) { return j < JF1 ? (int)threadIdx.x + j * kBlock : JF1 * kBlock + wave * T1 + lane; };
   auto elem2 = [&](int j) { return j < JF2 ? (int)threadIdx.x + j * kBlock : JF2 * kBlock + wave * T2 + lane; };
   unsigned off1[J1], off2[J2];
-  int c42[J2];
 #pragma unroll
   for (int j = 0; j < J1; ++j) {
     const int e = elem1(j), r = e / V1, c4 = e - r * V1;
@@ -264,7 +263,6 @@ __global__ __launch_bounds__(kBlock) void ica_accumulate2_kernel(LevelArgs a, So
   for (int j = 0; j < J2; ++j) {
     const int e = elem2(j), r = e / V2, c4 = e - r * V2;
     off2[j] = (unsigned)((r * W + 4 * c4) * 4);
-    c42[j] = 4 * c4;
   }
 
   // issue the LDS-DMA copies of chunk k into buffer `buf` (no waits here)
@@ -279,11 +277,12 @@ __global__ __launch_bounds__(kBlock) void ica_accumulate2_kernel(LevelArgs a, So
     if (w4) {
       // a skipped (all-frame) chunk still issues its copies, with every lane out of range, to keep the count
       const bool skip = (px & (1 << 29)) != 0;
-      const unsigned base1 = (unsigned)(((yc0 - 1) * W + x_t0) * 4);  // may wrap below 0: then out of range
+      // may wrap below 0 (row -1): then out of range.  A skipped chunk gets an out-of-range base.
+      const unsigned base1 = skip ? 0x40000000u : (unsigned)(((yc0 - 1) * W + x_t0) * 4);
 #pragma unroll
       for (int j = 0; j < J1; ++j) {
         float* dst = b1 + (j < JF1 ? wave * 64 + j * kBlock : JF1 * kBlock + wave * T1) * 4;
-        const unsigned o = (skip || off1[j] == kPoison) ? kPoison : off1[j] + base1;
+        const unsigned o = off1[j] + base1;  // a poisoned offset (>= 2^31) stays out of range after the add
         // tail lanes past the wave's share must not take part at all: an out-of-range lane still writes its
         // (zero) result to LDS, which would land in another wave's slots
         if (j < JF1 || lane < T1) {
@@ -305,7 +304,7 @@ __global__ __launch_bounds__(kBlock) void ica_accumulate2_kernel(LevelArgs a, So
 #pragma unroll
         for (int j = 0; j < J2; ++j) {
           float* dst = b2 + (j < JF2 ? wave * 64 + j * kBlock : JF2 * kBlock + wave * T2) * 4;
-          const unsigned o = (c42[j] >= (bw & 0xFFFF)) ? kPoison : off2[j] + base2;
+          const unsigned o = off2[j] + base2;  // all P2 columns of the row are copied (a few more than needed)
           if (j < JF2 || lane < T2) {
 #pragma unroll
             for (int c = 0; c < C; ++c)
