@@ -277,6 +277,7 @@ int launch_pyramid_down(ica_ctx* ctx, int batch, int C, int H, int W, int h, int
 
 // ICA_ACCUM=1 selects the simple direct-gather kernel (kept as an in-library cross-check of the LDS-staged one)
 int g_accum_variant = 2;
+int g_fold_hessian = 1;
 int g_fuse_solve = 0;  // ICA_FUSE_SOLVE=n: fuse the per-pair solve into the iteration kernel (last-arriving tile solves)
                       // when <= n pairs are left.  Measured slower than the separate solve kernel at every n on
                       // configs[1] (6.41-6.55 ms vs 6.25 ms per step), so it is off by default; kept, tested, as an option.
@@ -421,6 +422,7 @@ int ica_create(int device, ica_ctx** out) {
   if (const char* e = getenv("ICA_POLL_EVERY")) c->poll_every = std::max(1, atoi(e));
   if (const char* e = getenv("ICA_ACCUM")) g_accum_variant = (atoi(e) == 1) ? 1 : 2;
   if (const char* e = getenv("ICA_FUSE_SOLVE")) g_fuse_solve = atoi(e);
+  if (const char* e = getenv("ICA_SEPARATE_HESSIAN")) g_fold_hessian = atoi(e) == 0;
   *out = c;
   return ICA_OK;
 }
@@ -545,7 +547,11 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
     la.partials = ctx->partials.as<double>();
     la.n_pairs = B;
 
-    if (!robust) {  // ref :96-103: steepest-descent Hessian and its inverse, once per level
+    // L2 (ref :96-103): the steepest-descent Hessian does not depend on p and is needed once per level.  Instead of a
+    // separate pass over I1, iteration 0 runs the kernel variant that accumulates H next to b (weights identically 1)
+    // and its solve stores inv(H) for the remaining iterations.  ICA_SEPARATE_HESSIAN=1 restores the separate pass.
+    const bool l2_fold_hessian = !robust && g_fold_hessian;
+    if (!robust && !l2_fold_hessian) {
       la.act_list = nullptr; la.act_count = nullptr; la.host_slot = nullptr;
       launch_accumulate_mode(kModeHessian, tt, C, dim3(g[s].tiles, B), st, la);
       hipLaunchKernelGGL(ica_setup_solve_kernel, dim3(B), dim3(kSolveThreads), 0, st, la.partials, g[s].tiles, n,
@@ -590,9 +596,13 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
       sa.cur_list = lists + (size_t)cur * B; sa.cur_count = counts + cur;
       sa.nxt_list = lists + (size_t)nxt * B; sa.nxt_count = counts + nxt; sa.clr_count = counts + clr;
       sa.count_hist = ctx->count_hist.as<int>(); sa.trace = trace_out;
+      const bool first_l2 = l2_fold_hessian && it == 0;
+      sa.invert_h = robust || first_l2;  // the solve inverts the H it receives ...
+      sa.store_hinv = first_l2;          // ... and keeps the inverse for the later L2 iterations
+      la.robust_type = first_l2 ? (int)ICA_QUADRATIC : pr->robust_type;
       const bool fuse = nb <= g_fuse_solve && g_accum_variant == 2;
       sa.tickets = fuse ? ctx->tickets.as<int>() : nullptr;
-      launch_accumulate_mode(robust ? kModeRobust : kModeL2, tt, C, dim3(lg.tiles, nb), st, la, sa);
+      launch_accumulate_mode((robust || first_l2) ? kModeRobust : kModeL2, tt, C, dim3(lg.tiles, nb), st, la, sa);
       if (ctx->profiling && s == 0) {
         ICA_TRY(next_event(&e1));
         ICA_HIP(ctx, hipEventRecord(ctx->ev_pool[e1], st));

@@ -300,6 +300,8 @@ struct SolveArgs {
   int* clr_count;
   int* count_hist;        // [nscales][max_iter]
   double* trace;          // nullable [B][nscales][max_iter][10]
+  int invert_h;           // this launch carries H partials: invert them (robust loop; L2: first iteration of a level)
+  int store_hinv;         // L2, first iteration of a level: keep inv(H) in Hinv[pair] for the next iterations
   int* tickets;           // [B] arrival counters of the fused (last-tile-solves) mode; nullptr: separate solve kernel
 };
 
@@ -356,15 +358,17 @@ __device__ __forceinline__ void solve_pair(const SolveArgs& a, int slot, int pai
   double* Hm = scratch + 5 * kAccStride;
   double* Hi = Hm + kMaxN * kMaxN;
   double* ws = Hi + kMaxN * kMaxN;
-  gather_partials(a.partials, slot, a.tiles, s, scratch + kAccStride, 0, a.robust ? kAccStride : kMaxN);
+  gather_partials(a.partials, slot, a.tiles, s, scratch + kAccStride, 0, a.invert_h ? kAccStride : kMaxN);
   if (threadIdx.x != 0) return;
   const int n = a.n;
   const double* hinv = a.Hinv + (size_t)pair * 64;
-  if (a.robust) {
+  if (a.invert_h) {
     for (int k = 0; k < n; ++k)
       for (int m = k; m < n; ++m) Hm[k * kMaxN + m] = Hm[m * kMaxN + k] = s[kMaxN + tri_index(k, m, n)];
     lu_inverse(n, Hm, Hi, kMaxN, ws);  // derivatives.py:110-130 (zeros if singular)
     hinv = Hi;
+    if (a.store_hinv)
+      for (int i = 0; i < kMaxN * kMaxN; ++i) a.Hinv[(size_t)pair * 64 + i] = Hi[i];
   }
   double dp[kMaxN], e2 = 0.0;
   for (int i = 0; i < n; ++i) {  // image_optimisation.py:146-155
