@@ -270,3 +270,40 @@ def test_fused_solve_option_gives_the_same_iterates(eng, monkeypatch):
         outs.append(np.load(path))
     np.testing.assert_array_equal(outs[0][-32:], outs[1][-32:])          # iteration counts
     np.testing.assert_allclose(outs[0][:-32], outs[1][:-32], rtol=1e-9, atol=1e-12)
+
+
+EDGE = [
+    # name, H, W, C, t, r, ns, delta, nanifoutside, p0
+    ("odd_width_dword_copy_path", 90, 101, 3, oc.HOMOGRAPHY, oc.LORENTZIAN, 2, 5, True, None),
+    ("odd_width_affine_l2", 75, 83, 1, oc.AFFINITY, oc.QUADRATIC, 2, 4, True, None),
+    ("narrower_than_a_tile", 48, 40, 3, oc.SIMILARITY, oc.QUADRATIC, 1, 3, True, None),
+    ("tiny_image", 24, 24, 1, oc.TRANSLATION, oc.CHARBONNIER, 1, 2, True, None),
+    ("no_nan_frame_delta0", 64, 96, 3, oc.EUCLIDEAN, oc.QUADRATIC, 1, 0, True, None),
+    ("nanifoutside_false", 64, 96, 1, oc.AFFINITY, oc.GERMAN_MCCLURE, 1, 10, False, None),
+    ("frame_swallows_everything", 32, 48, 1, oc.AFFINITY, oc.QUADRATIC, 1, 40, True, None),          # H = 0 -> dp = 0
+    ("warp_entirely_outside", 64, 96, 1, oc.TRANSLATION, oc.QUADRATIC, 1, 5, True, [500.0, 300.0]),  # b = 0
+    ("warp_entirely_outside_robust", 64, 96, 3, oc.HOMOGRAPHY, oc.CHARBONNIER, 1, 5, True,
+     [0.0, 0.0, 900.0, 0.0, 0.0, -700.0, 0.0, 0.0]),
+    ("five_scales_small", 320, 416, 1, oc.EUCLIDEAN, oc.QUADRATIC, 5, 2, True, None),               # 20x26 at the top
+]
+
+
+@pytest.mark.parametrize("case", EDGE, ids=[c[0] for c in EDGE])
+def test_edge_cases_match_oracle(eng, case):
+    name, H_, W_, C, t, r, ns, delta, nanif, p0 = case
+    n = oc.nparams(t)
+    I1, I2, _ = syn.make_pair(4000 + H_ + W_, H_, W_, C, t, robust_clutter=(r != 0))
+    prob = eng.problem(1, H_, W_, C, t, r, nscales=ns, delta=delta, nanifoutside=nanif)
+    pin = None if p0 is None else torch.tensor([p0], dtype=torch.float64)
+    res = eng.solve(to_dev(eng, I1), to_dev(eng, I2), prob, p0=pin, want_images=True)
+    p_w, e_w, DI_w, Iw_w, nit_w = oc.ica_pyramidal(I1.astype(np.float64), I2.astype(np.float64),
+                                                   np.zeros(n) if p0 is None else np.array(p0, dtype=np.float64), t, ns, 0.5,
+                                                   1e-3, r, 0.0, nanif, delta)
+    assert list(res.niter[0].cpu().numpy()) == nit_w, name
+    p = res.p[0, :n].cpu().numpy()
+    scale = max(np.linalg.norm(p_w), 1e-3)
+    assert np.linalg.norm(p - p_w) / scale <= 1e-4, (name, p, p_w)
+    np.testing.assert_allclose(float(res.error[0]), e_w, rtol=2e-2, atol=1e-6)
+    Iw = to_np(res.Iw)[0]
+    assert np.array_equal(np.isnan(Iw), np.isnan(Iw_w)), name
+    np.testing.assert_allclose(np.nan_to_num(Iw), np.nan_to_num(Iw_w), atol=2e-2)
