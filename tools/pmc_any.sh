@@ -11,8 +11,13 @@ for fn in glob.glob('/tmp/pmc_$tag/*/*counter_collection.csv'):
         k = r['Kernel_Name']
         if '$pat' not in k: continue
         agg[k.split('(')[0][-40:]][r['Counter_Name']].append(float(r['Counter_Value']))
+dur = collections.defaultdict(list)
+for fn in glob.glob('/tmp/pmc_$tag/*/*kernel_trace.csv'):
+    for r in csv.DictReader(open(fn)):
+        if '$pat' in r['Kernel_Name']:
+            dur[r['Kernel_Name'].split('(')[0][-40:]].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
 for k, d in agg.items():
-    print(k)
+    print(k, "avg_us=%.1f" % (sum(dur[k]) / max(1, len(dur[k]))) if k in dur else "")
     for c, v in sorted(d.items()):
         print(f"   {c:<28} n={len(v):<3} max={max(v):.4g} mean={sum(v)/len(v):.4g}")
 PY
