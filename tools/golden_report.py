@@ -3,7 +3,8 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from tests import test_golden as tg
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+import test_golden as tg
 for run in tg.CFG_RUNS:
     n = tg.oc.nparams(run["transform"])
     res = tg._hip_solve(run)
