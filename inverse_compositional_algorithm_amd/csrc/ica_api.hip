@@ -43,10 +43,9 @@ struct DevBuf {
 struct DeviceBandOp {
   DevBuf start, wT, vj0, vspan, vown0, vown1, vw;
   int n_in = 0, n_out = 0, K = 0;
-  int vspan_max = 0;   // widest input span of 8 consecutive outputs (window of both passes)
+  int vspan_max = 0;   // widest input span of kOutsV consecutive outputs (window of the vertical pass)
   int span_pad = 0;    // LDS row pitch (floats) of the horizontal pass: widest 64-output input span, made odd
   bool vcover = false; // the groups' "own" ranges cover the whole input axis (min/max can be folded into the pass)
-  bool hcover = false; // the 64-output tiles' input spans cover the whole input axis (fused pyramid step)
   BandOp view() const {
     return BandOp{start.as<int>(), wT.as<float>(), vj0.as<int>(), vspan.as<int>(), vown0.as<int>(), vown1.as<int>(),
                   vw.as<float>(), n_in, n_out, K};
@@ -71,7 +70,6 @@ struct ica_ctx {
   DevBuf pyr1[ICA_MAX_SCALES], pyr2[ICA_MAX_SCALES];  // levels >= 1
   DevBuf tmp_resample;                                // intermediate of the separable pyramid pass
   DevBuf partials, hinv, p_prev, lambda_it, error, niter, lists, counts, count_hist, minmax, mm_part, mm_in, tickets;
-  DevBuf clip_flag;                                   // per pair: the fused pyramid step needs its clip pass
   DevBuf scratch_p;
   int* pinned_count = nullptr;   // 4 ints for synchronous reads + a [scales][max_iter] board the kernels post to
   int* board = nullptr;          // host pointer of the board (pinned, host-coherent)
@@ -88,7 +86,7 @@ struct ica_ctx {
     for (auto e : ev_pool) (void)hipEventDestroy(e);
     for (int i = 0; i < ICA_MAX_SCALES; ++i) { pyr1[i].release(); pyr2[i].release(); }
     DevBuf* all[] = {&tmp_resample, &partials, &hinv, &p_prev, &lambda_it, &error, &niter, &lists, &counts,
-                     &count_hist, &minmax, &mm_part, &mm_in, &tickets, &scratch_p, &clip_flag};
+                     &count_hist, &minmax, &mm_part, &mm_in, &tickets, &scratch_p};
     for (auto* b : all) b->release();
     if (pinned_count) (void)hipHostFree(pinned_count);
     if (board) (void)hipHostFree(board);
@@ -166,7 +164,7 @@ int get_op(ica_ctx* ctx, int n_in, int n_out, DeviceBandOp** out) {
   d->n_in = n_in;
   d->n_out = n_out;
   d->K = h.K;
-  // vertical pass: per group of 8 outputs, a zero-padded window of weights indexed by input row
+  // vertical pass: per group of kOutsV outputs, a zero-padded window of weights indexed by input row
   const int groups = (n_out + kOutsV - 1) / kOutsV;
   std::vector<int> vj0(groups), vspan(groups);
   std::vector<float> vw((size_t)groups * kVWin * kOutsV, 0.0f);
@@ -194,12 +192,7 @@ int get_op(ica_ctx* ctx, int n_in, int n_out, DeviceBandOp** out) {
     if (vown0[g] < vj0[g] || vown1[g] > vj0[g] + vspan[g] || vown1[g] < vown0[g]) d->vcover = false;
   {
     int span = 1;
-    d->hcover = h.start[0] == 0 && h.start[n_out - 1] + h.K >= n_in;
-    for (int o = 0; o < n_out; o += 64) {
-      const int end = h.start[std::min(o + 63, n_out - 1)] + h.K;
-      span = std::max(span, end - h.start[o]);
-      if (o + 64 < n_out && h.start[o + 64] > end) d->hcover = false;  // a gap between the spans of two tiles
-    }
+    for (int o = 0; o < n_out; o += 64) span = std::max(span, h.start[std::min(o + 63, n_out - 1)] + h.K - h.start[o]);
     d->span_pad = span | 1;
   }
   auto up = [&](DevBuf& b, const void* src, size_t bytes) -> hipError_t {
@@ -237,13 +230,10 @@ int launch_minmax(ica_ctx* ctx, int batch, size_t elems, const float* img, float
   return ICA_OK;
 }
 
-int g_fused_pyramid = 1;  // ICA_FUSED_PYRAMID=0 keeps the two-pass (vertical, horizontal) pyramid step
-
 // One pyramid step.  `mm_out` ([batch][2]) receives the min/max of `in` (the clip range of skimage's rescale, and --
-// for I2 -- of the warp at that level); it is folded into the pass that reads every pixel of `in` anyway.
-// `mm_next` (nullable) receives the min/max of `out`.
+// for I2 -- of the warp at that level); it is folded into the vertical pass, which reads every pixel of `in` anyway.
 int launch_pyramid_down(ica_ctx* ctx, int batch, int C, int H, int W, int h, int w, const float* in, float* out,
-                        float* mm_out, float* mm_next = nullptr) {
+                        float* mm_out) {
   DeviceBandOp *ox = nullptr, *oy = nullptr;
   ICA_TRY(get_op(ctx, W, w, &ox));
   ICA_TRY(get_op(ctx, H, h, &oy));
@@ -252,32 +242,6 @@ int launch_pyramid_down(ica_ctx* ctx, int batch, int C, int H, int W, int h, int
   if (lds > 64 * 1024 || oy->vspan_max > kVWin) {
     ctx->last_error = "pyramid step: downsampling factor too large for the tiled resampling passes";
     return ICA_EINVAL_ARG;
-  }
-  // planes ride on grid.z (<= 65535): chunk on whole pairs so the per-pair indices stay aligned
-  const int step = std::max(C, (32768 / C) * C);
-  if (g_fused_pyramid && oy->vcover && ox->hcover) {
-    const int vgroups = (h + kOutsV - 1) / kOutsV, xtiles = (w + 63) / 64;
-    const int per_pair = C * vgroups * xtiles;
-    ICA_HIP(ctx, ctx->mm_part.ensure((size_t)batch * per_pair * 4 * sizeof(float)));
-    ICA_HIP(ctx, ctx->clip_flag.ensure((size_t)batch * sizeof(int)));
-    float* ranges = ctx->mm_part.as<float>();
-    for (int p0 = 0; p0 < planes; p0 += step) {
-      const int np = std::min(step, planes - p0);
-      hipLaunchKernelGGL(ica_rescale_fused_kernel, dim3(xtiles, (vgroups + kWaves - 1) / kWaves, np), dim3(kBlock), lds,
-                         ctx->stream, in + (size_t)p0 * H * W, out + (size_t)p0 * h * w, np, oy->view(), ox->view(),
-                         ox->span_pad, ranges + (size_t)p0 * vgroups * xtiles * 4);
-    }
-    hipLaunchKernelGGL(ica_rescale_ranges_kernel, dim3((batch + 255) / 256), dim3(256), 0, ctx->stream, ranges, per_pair,
-                       batch, mm_out, mm_next, ctx->clip_flag.as<int>());
-    const size_t elems = (size_t)C * h * w;
-    const int chunks = (int)std::max<size_t>(1, std::min<size_t>(64, elems / ((size_t)kBlock * 16)));
-    for (int b0 = 0; b0 < batch; b0 += 32768) {
-      const int nb = std::min(32768, batch - b0);
-      hipLaunchKernelGGL(ica_clip_kernel, dim3(chunks, nb), dim3(kBlock), 0, ctx->stream, out + (size_t)b0 * elems, elems,
-                         mm_out + (size_t)b0 * 2, ctx->clip_flag.as<int>() + b0);
-    }
-    ICA_HIP(ctx, hipGetLastError());
-    return ICA_OK;
   }
   ICA_HIP(ctx, ctx->tmp_resample.ensure((size_t)planes * h * W * sizeof(float)));
   float* tmp = ctx->tmp_resample.as<float>();
@@ -290,6 +254,8 @@ int launch_pyramid_down(ica_ctx* ctx, int batch, int C, int H, int W, int h, int
   } else {
     ICA_TRY(launch_minmax(ctx, batch, (size_t)C * H * W, in, mm_out));
   }
+  // planes ride on grid.z (<= 65535): chunk on whole pairs so the per-pair indices stay aligned
+  const int step = std::max(C, (32768 / C) * C);
   for (int p0 = 0; p0 < planes; p0 += step) {
     const int np = std::min(step, planes - p0);
     hipLaunchKernelGGL(ica_resample_v_kernel, dim3(xblocks, (vgroups + kWaves - 1) / kWaves, np), dim3(kBlock), 0, ctx->stream,
@@ -306,7 +272,6 @@ int launch_pyramid_down(ica_ctx* ctx, int batch, int C, int H, int W, int h, int
                        mm_out + (size_t)(p0 / C) * 2, ox->span_pad);
   }
   ICA_HIP(ctx, hipGetLastError());
-  if (mm_next) ICA_TRY(launch_minmax(ctx, batch, (size_t)C * h * w, out, mm_next));
   return ICA_OK;
 }
 
@@ -458,7 +423,6 @@ int ica_create(int device, ica_ctx** out) {
   if (const char* e = getenv("ICA_ACCUM")) g_accum_variant = (atoi(e) == 1) ? 1 : 2;
   if (const char* e = getenv("ICA_FUSE_SOLVE")) g_fuse_solve = atoi(e);
   if (const char* e = getenv("ICA_SEPARATE_HESSIAN")) g_fold_hessian = atoi(e) == 0;
-  if (const char* e = getenv("ICA_FUSED_PYRAMID")) g_fused_pyramid = atoi(e) != 0;
   *out = c;
   return ICA_OK;
 }
@@ -534,13 +498,12 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
   for (int s = 1; s < ns; ++s) {
     ICA_TRY(launch_pyramid_down(ctx, B, C, g[s - 1].H, g[s - 1].W, g[s].H, g[s].W, L1[s - 1], ctx->pyr1[s].as<float>(),
                                 ctx->mm_in.as<float>()));
-    // the coarsest level is not read by another pyramid step: its range comes with the step that produces it
     ICA_TRY(launch_pyramid_down(ctx, B, C, g[s - 1].H, g[s - 1].W, g[s].H, g[s].W, L2[s - 1], ctx->pyr2[s].as<float>(),
-                                mm2 + (size_t)(s - 1) * B * 2, s == ns - 1 ? mm2 + (size_t)s * B * 2 : nullptr));
+                                mm2 + (size_t)(s - 1) * B * 2));
     L1[s] = ctx->pyr1[s].as<float>();
     L2[s] = ctx->pyr2[s].as<float>();
   }
-  if (ns == 1) ICA_TRY(launch_minmax(ctx, B, (size_t)C * g[0].H * g[0].W, L2[0], mm2));
+  ICA_TRY(launch_minmax(ctx, B, (size_t)C * g[ns - 1].H * g[ns - 1].W, L2[ns - 1], mm2 + (size_t)(ns - 1) * B * 2));
   if (ctx->board_dirty) ICA_HIP(ctx, hipStreamSynchronize(st));  // nothing may post to the board while it is reset
   for (size_t i = 0; i < (size_t)ns * std::max(1, max_iter); ++i) ctx->board[i] = -1;
   ctx->board_dirty = true;

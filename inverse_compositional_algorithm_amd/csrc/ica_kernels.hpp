@@ -606,21 +606,21 @@ __global__ void ica_zoom_params_kernel(int batch, int tt, int w, int h, int ww, 
 struct BandOp {
   const int* start;    // [n_out] first input index of the band
   const float* wT;     // [K][n_out] weights (horizontal pass of the generic fallback)
-  const int* vj0;      // [groups] first input index of each group of 8 outputs
+  const int* vj0;      // [groups] first input index of each group of kOutsV outputs
   const int* vspan;    // [groups] input samples spanned by the group
   const int* vown0;    // [groups] the groups' windows overlap; [vown0, vown1) partitions the input axis so that the
   const int* vown1;    //          vertical pass can fold the image's min/max into its single read
-  const float* vw;     // [groups][kVWin][8] zero-padded weight window, 8 outputs interleaved
+  const float* vw;     // [groups][kVWin][kOutsV] zero-padded weight window, kOutsV outputs interleaved
   int n_in, n_out, K;
 };
 
-constexpr int kOutsV = 8;    // consecutive outputs per wave in both passes
-constexpr int kVWin = 96;    // max input samples spanned by 8 consecutive outputs (8*f + K), checked on the host
+constexpr int kOutsV = 16;   // consecutive output rows per wave in the vertical pass
+constexpr int kVWin = 160;   // max input samples spanned by 16 consecutive outputs (16*f + K), checked on the host
 constexpr int kRowsH = 32;   // rows per workgroup in the horizontal pass (8 per wave)
 
 // Vertical pass: in [planes][n_in][W] -> out [planes][n_out][W]  (+ optional min/max of `in` per pair).
-// lane = column (coalesced 256-B row segments); each wave produces 8 consecutive output rows, so every input
-// value is loaded once and feeds 8 FMAs whose weights are wave-uniform: they come through the scalar cache into
+// lane = column (coalesced 256-B row segments); each wave produces kOutsV consecutive output rows, so every input
+// value is loaded once and feeds kOutsV FMAs whose weights are wave-uniform: they come through the scalar cache into
 // SGPRs (s_load_dwordx8/x16 per input row), the vector ALU only sees v_fmac / v_pk_fma(acc, sgpr, value).
 // The operator weights are float64 on the host (ica_pyramid.hpp); they are applied in fp32 like every other
 // per-pixel quantity of the engine (the result is stored as fp32 anyway).
@@ -744,145 +744,6 @@ __global__ __launch_bounds__(kBlock) void ica_resample_h_kernel(const float* __r
     const int y = r_base + rg * 8 + i;
     if (y < H) out[((size_t)pl * H + y) * op.n_out + o] = fminf(fmaxf(acc[i], lo), hi);
   }
-}
-
-// ---- fused pyramid step ---------------------------------------------------------------------------------
-// Vertical and horizontal pass of one rescale() in ONE kernel: the intermediate image (half the rows, all the
-// columns) never goes to HBM.  A wave owns 8 output rows x 64 output columns:
-//   V: for each 64-column group of the input span of its 64 outputs, lane = input column, the input rows of the
-//      group's window stream through registers (each value feeds 8 FMAs with SGPR weights, as in
-//      ica_resample_v_kernel) and the 8 results go to the wave's own LDS rows (de-interleaved even / odd columns);
-//   H: lane = output column, K taps from those LDS rows (as in ica_resample_h_kernel), 8 rows per weight load.
-// No workgroup barrier is needed for correctness of the data flow (a wave reads only what it wrote); the four
-// waves of a workgroup are four consecutive row groups.
-// The clip of skimage's rescale needs the min/max of the WHOLE input image, which is only known when every tile
-// has been read -- so the result is stored unclipped, each wave posts the range of the input rows it owns and of
-// its outputs, and ica_rescale_ranges_kernel + ica_clip_kernel finish the job (the clip kernel exits at once for
-// the pairs -- nearly all -- whose output range already lies inside the input range).
-__global__ __launch_bounds__(kBlock) void ica_rescale_fused_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                                   int planes, BandOp opv, BandOp oph, int span_pad,
-                                                                   float* __restrict__ ranges) {
-  extern __shared__ float tile[];  // [4 waves][8 rows][span_pad]
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int g = blockIdx.y * kWaves + wave;  // group of 8 output rows
-  const int pl = blockIdx.z;
-  const int H = opv.n_in, W = oph.n_in, h = opv.n_out, w = oph.n_out;
-  const int o0 = g * kOutsV;
-  if (o0 >= h) return;  // whole wave (no barrier below)
-  const int no = min(kOutsV, h - o0);
-  const int ob = blockIdx.x * 64, ol = min(ob + 63, w - 1);
-  const int c0 = oph.start[ob];
-  const int span = oph.start[ol] + oph.K - c0;  // <= span_pad
-  const int half = (span_pad + 1) >> 1;
-  const int j0 = opv.vj0[g], vspan = opv.vspan[g];
-  const int own0 = opv.vown0[g] - j0, own1 = opv.vown1[g] - j0;
-  const float* __restrict__ wz = opv.vw + (size_t)g * kVWin * kOutsV;
-  float* T = tile + wave * kOutsV * span_pad;
-  const float* src = in + (size_t)pl * H * W + (size_t)j0 * W;
-  float in_lo = INFINITY, in_hi = -INFINITY;
-
-  for (int cb = 0; cb < span; cb += 64) {
-    const int c = cb + lane, xg = c0 + c;
-    const bool active = (c < span) & (xg < W);
-    const float* col = src + (active ? xg : 0);
-    float acc[kOutsV];
-#pragma unroll
-    for (int i = 0; i < kOutsV; ++i) acc[i] = 0.f;
-    float lo = INFINITY, hi = -INFINITY;
-    auto run = [&](int a, int b, auto track_c) {  // rows [a, b) of the window; track_c: fold them into min/max
-      constexpr bool TRACK = decltype(track_c)::value;
-#pragma unroll 4
-      for (int jj = a; jj < b; ++jj) {
-        const float v = col[(size_t)jj * W];
-        if constexpr (TRACK) { lo = fminf(lo, v); hi = fmaxf(hi, v); }
-#pragma unroll
-        for (int i = 0; i < kOutsV; ++i) acc[i] = fmaf(wz[jj * kOutsV + i], v, acc[i]);
-      }
-    };
-    run(0, own0, std::false_type{});
-    run(own0, own1, std::true_type{});
-    run(own1, vspan, std::false_type{});
-    if (active) {  // (inactive lanes re-read column 0 of the span: real pixels, but not theirs to report or store)
-      in_lo = fminf(in_lo, lo);
-      in_hi = fmaxf(in_hi, hi);
-    }
-    if (c < span) {
-      float* t = T + (c & 1) * half + (c >> 1);
-#pragma unroll
-      for (int i = 0; i < kOutsV; ++i) t[i * span_pad] = active ? acc[i] : 0.0f;
-    }
-  }
-  // the wave reads back only its own LDS rows: its own LDS writes must have landed, nothing else
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-
-  float out_lo = INFINITY, out_hi = -INFINITY;
-  const int o = ob + lane;
-  if (o < w) {
-    const int s = oph.start[o] - c0;
-    float acc[kOutsV];
-#pragma unroll
-    for (int i = 0; i < kOutsV; ++i) acc[i] = 0.f;
-#pragma unroll 2
-    for (int k = 0; k < oph.K; ++k) {
-      const float wk = oph.wT[(size_t)k * w + o];
-      const int c = s + k;
-      const float* q = T + (c & 1) * half + (c >> 1);
-#pragma unroll
-      for (int i = 0; i < kOutsV; ++i) acc[i] = fmaf(wk, q[i * span_pad], acc[i]);
-    }
-#pragma unroll
-    for (int i = 0; i < kOutsV; ++i) {
-      if (i < no) {
-        out[((size_t)pl * h + o0 + i) * w + o] = acc[i];
-        out_lo = fminf(out_lo, acc[i]);
-        out_hi = fmaxf(out_hi, acc[i]);
-      }
-    }
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    in_lo = fminf(in_lo, __shfl_down(in_lo, off, 64));
-    in_hi = fmaxf(in_hi, __shfl_down(in_hi, off, 64));
-    out_lo = fminf(out_lo, __shfl_down(out_lo, off, 64));
-    out_hi = fmaxf(out_hi, __shfl_down(out_hi, off, 64));
-  }
-  if (lane == 0) {
-    const int ngroups = (h + kOutsV - 1) / kOutsV;
-    float* r = ranges + (((size_t)pl * ngroups + g) * gridDim.x + blockIdx.x) * 4;  // [plane][group][column tile]
-    r[0] = in_lo; r[1] = in_hi; r[2] = out_lo; r[3] = out_hi;
-  }
-}
-
-// Per pair: range of the input image -> mm_in (the clip range), range of the clipped output -> mm_next (nullable),
-// and whether any output lies outside the clip range at all.
-__global__ void ica_rescale_ranges_kernel(const float* __restrict__ ranges, int per_pair, int batch,
-                                          float* __restrict__ mm_in, float* __restrict__ mm_next, int* __restrict__ need_clip) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= batch) return;
-  float il = INFINITY, ih = -INFINITY, ol = INFINITY, oh = -INFINITY;
-  for (int c = 0; c < per_pair; ++c) {
-    const float* r = ranges + ((size_t)b * per_pair + c) * 4;
-    il = fminf(il, r[0]); ih = fmaxf(ih, r[1]); ol = fminf(ol, r[2]); oh = fmaxf(oh, r[3]);
-  }
-  mm_in[b * 2] = il;
-  mm_in[b * 2 + 1] = ih;
-  need_clip[b] = (ol < il) | (oh > ih);
-  if (mm_next) {
-    mm_next[b * 2] = fminf(fmaxf(ol, il), ih);
-    mm_next[b * 2 + 1] = fminf(fmaxf(oh, il), ih);
-  }
-}
-
-// np.clip(out, in.min(), in.max()) of the pairs that need it (grid: chunks x pairs)
-__global__ __launch_bounds__(kBlock) void ica_clip_kernel(float* __restrict__ img, size_t elems, const float* __restrict__ mm,
-                                                          const int* __restrict__ need_clip) {
-  const int b = blockIdx.y;
-  if (!need_clip[b]) return;
-  const float lo = mm[b * 2], hi = mm[b * 2 + 1];
-  float* p = img + (size_t)b * elems;
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < elems; i += (size_t)gridDim.x * kBlock)
-    p[i] = fminf(fmaxf(p[i], lo), hi);
 }
 
 }  // namespace ica
