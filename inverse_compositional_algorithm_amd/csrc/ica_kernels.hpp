@@ -311,7 +311,36 @@ struct SolveArgs {
 constexpr int kSolveThreads = 256;
 constexpr int kSolveScratch = 5 * kAccStride + 2 * kMaxN * kMaxN + kLuWork;  // doubles of LDS a solve needs
 __device__ __forceinline__ void gather_partials(const double* partials, int slot, int tiles, double* s /*LDS[44]*/,
-                                                double* part /*LDS[4][44]*/, int k_lo = 0, int k_hi = kAccStride) {
+                                                double* part /*LDS[4][44], or [32][8] for the b-only case*/,
+                                                int k_lo = 0, int k_hi = kAccStride) {
+  if (k_lo == 0 && k_hi <= kMaxN) {
+    // b only (every L2 iteration after the first): 8 sums over the tiles.  All 256 threads load -- 32 tile groups x
+    // 8 values, a thread's loads all in flight together -- because with hundreds of tiles (short tiles of the late,
+    // small launches) this gather IS the latency of the solve.  Fixed summation order.
+    const int k = threadIdx.x & 7, g = threadIdx.x >> 3;
+    const double* q = partials + (size_t)slot * tiles * kAccStride + k;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int t = g;
+    for (; t + 96 < tiles; t += 128) {
+      a0 += q[(size_t)t * kAccStride];
+      a1 += q[(size_t)(t + 32) * kAccStride];
+      a2 += q[(size_t)(t + 64) * kAccStride];
+      a3 += q[(size_t)(t + 96) * kAccStride];
+    }
+    for (; t < tiles; t += 32) a0 += q[(size_t)t * kAccStride];
+    part[g * 8 + k] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (threadIdx.x < kAccStride) {
+      double v = 0.0;
+      if (threadIdx.x < k_hi) {
+#pragma unroll
+        for (int gg = 0; gg < 32; ++gg) v += part[gg * 8 + threadIdx.x];
+      }
+      s[threadIdx.x] = v;
+    }
+    __syncthreads();
+    return;
+  }
   const int k = threadIdx.x & 63, g = threadIdx.x >> 6;
   if (k >= k_lo && k < k_hi) {
     const double* q = partials + (size_t)slot * tiles * kAccStride + k;

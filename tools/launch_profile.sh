@@ -9,7 +9,8 @@ rows = []
 for fn in glob.glob('/tmp/lp_$tag/*/*kernel_trace.csv'):
     rows += list(csv.DictReader(open(fn)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-acc = [r for r in rows if 'accumulate2' in r['Kernel_Name']]
+import os
+acc = [r for r in rows if os.environ.get('LP_KERNEL', 'accumulate2') in r['Kernel_Name']]
 half = acc[len(acc) // 2:]   # the timed solve (second of two)
 tot = 0
 for r in half:
