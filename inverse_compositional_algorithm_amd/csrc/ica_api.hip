@@ -64,7 +64,6 @@ struct ica_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool profiling = false;
-  int poll_every = 3;
   std::string last_error;
   // workspaces
   DevBuf pyr1[ICA_MAX_SCALES], pyr2[ICA_MAX_SCALES];  // levels >= 1
@@ -419,7 +418,6 @@ int ica_create(int device, ica_ctx** out) {
   if (hipSetDevice(device) != hipSuccess) return ICA_ENODEVICE;
   auto* c = new ica_ctx();
   c->device = device;
-  if (const char* e = getenv("ICA_POLL_EVERY")) c->poll_every = std::max(1, atoi(e));
   if (const char* e = getenv("ICA_ACCUM")) g_accum_variant = (atoi(e) == 1) ? 1 : 2;
   if (const char* e = getenv("ICA_FUSE_SOLVE")) g_fuse_solve = atoi(e);
   if (const char* e = getenv("ICA_SEPARATE_HESSIAN")) g_fold_hessian = atoi(e) == 0;
