@@ -86,14 +86,20 @@ typedef struct ica_problem {
   double lambda_ratio;    /* constants.py:4 LAMBDA_RATIO = 0.9                                          */
 } ica_problem;
 
-/* Filled by ica_solve_batch*_ when stats != NULL (the call then synchronises). */
+/* Filled by ica_solve_batch*_ when stats != NULL (the call then synchronises).
+ * The iteration work of a scale is split by the kernel that did it: `iter_*` is the steady-state kernel
+ * (L2: ica_accumulate2_kernel<TT, b-only, C>, iterations >= 1; robust: <TT, H+b, C>, every iteration), `first_*` is the
+ * L2 path's first iteration of a level, which also accumulates the Hessian (<TT, H+b, C>; zeros for robust). */
 typedef struct ica_stats {
   int64_t pair_iterations[ICA_MAX_SCALES]; /* executed (pair, iteration) units per scale (0 = finest) */
   int64_t pair_iterations_total;
-  int64_t iter_launches[ICA_MAX_SCALES];   /* launches of the fused iteration kernel per scale          */
+  int64_t iter_launches[ICA_MAX_SCALES];   /* launches of the steady-state iteration kernel per scale   */
   double iter_kernel_ms[ICA_MAX_SCALES];   /* HIP-event time of those launches (profiling on), else 0   */
   double iter_kernel_bytes[ICA_MAX_SCALES];/* algorithmic bytes they processed: 2*H_l*W_l*C*4 per unit  */
   int32_t level_width[ICA_MAX_SCALES], level_height[ICA_MAX_SCALES];
+  int64_t first_launches[ICA_MAX_SCALES];  /* same three figures for the L2 first-iteration launches    */
+  double first_kernel_ms[ICA_MAX_SCALES];
+  double first_kernel_bytes[ICA_MAX_SCALES];
 } ica_stats;
 
 typedef struct ica_ctx ica_ctx;

@@ -31,7 +31,9 @@ class Stats(C.Structure):
     _fields_ = [("pair_iterations", C.c_int64 * ICA_MAX_SCALES), ("pair_iterations_total", C.c_int64),
                 ("iter_launches", C.c_int64 * ICA_MAX_SCALES), ("iter_kernel_ms", C.c_double * ICA_MAX_SCALES),
                 ("iter_kernel_bytes", C.c_double * ICA_MAX_SCALES), ("level_width", C.c_int32 * ICA_MAX_SCALES),
-                ("level_height", C.c_int32 * ICA_MAX_SCALES)]
+                ("level_height", C.c_int32 * ICA_MAX_SCALES),
+                ("first_launches", C.c_int64 * ICA_MAX_SCALES), ("first_kernel_ms", C.c_double * ICA_MAX_SCALES),
+                ("first_kernel_bytes", C.c_double * ICA_MAX_SCALES)]
 
 
 _P = C.c_void_p

@@ -513,7 +513,7 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
 
   int* lists = ctx->lists.as<int>();
   int* counts = ctx->counts.as<int>();
-  struct EvRec { int level; size_t e0, e1; };
+  struct EvRec { int level; size_t e0, e1; bool first; };
   std::vector<EvRec> evrecs;
   size_t ev_used = 0;
   auto next_event = [&](size_t* idx) -> int {
@@ -525,7 +525,7 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
     *idx = ev_used++;
     return ICA_OK;
   };
-  int64_t launches[ICA_MAX_SCALES] = {0};
+  int64_t launches[ICA_MAX_SCALES] = {0}, first_launches[ICA_MAX_SCALES] = {0};
 
   // ---- coarse to fine (ref :340-372) ----
   for (int s = ns - 1; s >= 0; --s) {
@@ -581,7 +581,7 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
       la.act_list = lists + (size_t)cur * B;
       la.act_count = counts + cur;
       size_t e0 = 0, e1 = 0;
-      if (ctx->profiling && s == 0) {  // the kernel quoted in the roofline: scale 0
+      if (ctx->profiling) {
         ICA_TRY(next_event(&e0));
         ICA_HIP(ctx, hipEventRecord(ctx->ev_pool[e0], st));
       }
@@ -601,12 +601,13 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
       const bool fuse = nb <= g_fuse_solve && g_accum_variant == 2;
       sa.tickets = fuse ? ctx->tickets.as<int>() : nullptr;
       launch_accumulate_mode((robust || first_l2) ? kModeRobust : kModeL2, tt, C, dim3(lg.tiles, nb), st, la, sa);
-      if (ctx->profiling && s == 0) {
+      if (ctx->profiling) {
         ICA_TRY(next_event(&e1));
         ICA_HIP(ctx, hipEventRecord(ctx->ev_pool[e1], st));
-        evrecs.push_back({s, e0, e1});
+        evrecs.push_back({s, e0, e1, first_l2});
       }
-      launches[s]++;
+      if (first_l2) first_launches[s]++;
+      else launches[s]++;
       if (!fuse) hipLaunchKernelGGL(ica_solve_kernel, dim3(nb), dim3(kSolveThreads), 0, st, sa);
     }
     ICA_HIP(ctx, hipGetLastError());
@@ -632,15 +633,19 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
       for (int it = 0; it < max_iter; ++it) units += hist[(size_t)s * max_iter + it];
       stats->pair_iterations[s] = units;
       stats->pair_iterations_total += units;
+      const double unit_bytes = 2.0 * g[s].H * g[s].W * C * 4.0;
+      const int64_t first_units = first_launches[s] ? hist[(size_t)s * max_iter] : 0;
       stats->iter_launches[s] = launches[s];
-      stats->iter_kernel_bytes[s] = (double)units * 2.0 * g[s].H * g[s].W * C * 4.0;
+      stats->iter_kernel_bytes[s] = (double)(units - first_units) * unit_bytes;
+      stats->first_launches[s] = first_launches[s];
+      stats->first_kernel_bytes[s] = (double)first_units * unit_bytes;
       stats->level_width[s] = g[s].W;
       stats->level_height[s] = g[s].H;
     }
     for (const auto& r : evrecs) {
       float ms = 0.f;
       ICA_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[r.e0], ctx->ev_pool[r.e1]));
-      stats->iter_kernel_ms[r.level] += ms;
+      (r.first ? stats->first_kernel_ms : stats->iter_kernel_ms)[r.level] += ms;
     }
   }
   return ICA_OK;

@@ -120,6 +120,9 @@ class IcaEngine:
                              iter_launches=list(st.iter_launches[:ns]),
                              iter_kernel_ms=list(st.iter_kernel_ms[:ns]),
                              iter_kernel_bytes=list(st.iter_kernel_bytes[:ns]),
+                             first_launches=list(st.first_launches[:ns]),
+                             first_kernel_ms=list(st.first_kernel_ms[:ns]),
+                             first_kernel_bytes=list(st.first_kernel_bytes[:ns]),
                              level_size=[(st.level_width[s], st.level_height[s]) for s in range(ns)])
         return res
 

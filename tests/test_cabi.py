@@ -35,7 +35,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 def test_struct_layout_matches_header(lib):
     from inverse_compositional_algorithm_amd._lib import Problem, Stats
     assert C.sizeof(Problem) == 12 * 4 + 6 * 8
-    assert C.sizeof(Stats) == 16 * 8 + 8 + 16 * 8 + 16 * 8 + 16 * 8 + 2 * 16 * 4
+    assert C.sizeof(Stats) == 16 * 8 + 8 + 16 * 8 + 16 * 8 + 16 * 8 + 2 * 16 * 4 + 3 * 16 * 8
     assert Problem.tol.offset == 48 and Problem.lambda_ratio.offset == 88
 
 
