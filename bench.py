@@ -13,6 +13,8 @@ Pairs are independent, so N GPUs run N shards of the same per-GPU batch with no 
 from __future__ import annotations
 
 import argparse
+import contextlib
+import threading
 import json
 import os
 import sys
@@ -32,6 +34,7 @@ CONFIGS = {
     5: dict(batch=1024, H=1080, W=1920, C=3, transform=5, robust=3, nscales=5,
             name="configs[4]: 1024 pairs/GPU 1920x1080x3, HOMOGRAPHY, LORENTZIAN, 5 scales"),
 }
+IN_FLIGHT_DEFAULT = 1
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 
 
@@ -77,6 +80,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="pairs per GPU (default: the config's)")
+    ap.add_argument("--in-flight", type=int, default=IN_FLIGHT_DEFAULT,
+                    help="solves kept in flight per GPU (one engine + HIP stream + host thread each): the straggler "
+                         "launches of one solve overlap the pyramid and coarse levels of the next")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -114,34 +120,70 @@ def main():
     def barrier():
         sharding.barrier(info, eng.device)
 
-    eng.set_profiling(True)
-    for _ in range(args.warmup):
-        res = eng.solve(I1, I2, prob, want_stats=True)
+    # D solves in flight: D engines (own workspaces, own HIP stream, own host thread -- the host follows each solve to
+    # size its launches), all reading the same resident batch.  Steps are handed out one by one, so exactly
+    # `steps` solves run between the two barriers however they interleave.
+    D = max(1, args.in_flight)
+    engines = [eng] + [IcaEngine(local) for _ in range(D - 1)]
+    for e in engines[1:]:
+        e.prepare(prob)
+    streams = [None] if D == 1 else [torch.cuda.Stream(device=eng.device) for _ in range(D)]
+    lock = threading.Lock()
+    acc = dict(units=0, dom_ms=0.0, dom_bytes=0.0, dom_n=0, s0_ms=0.0, s0_bytes=0.0, first_ms=0.0, n_prof=0, res=None,
+               latency=0.0)
+
+    def run_steps(n_steps, timed):
+        counter = iter(range(n_steps))
+
+        def worker(k):
+            torch.cuda.set_device(local)
+            ctx = torch.cuda.stream(streams[k]) if streams[k] is not None else contextlib.nullcontext()
+            with ctx:
+                while True:
+                    with lock:
+                        i = next(counter, None)
+                    if i is None:
+                        return
+                    prof = profiled(i) if timed else True
+                    engines[k].set_profiling(prof)
+                    t_s = time.perf_counter()
+                    r = engines[k].solve(I1, I2, prob, want_stats=True)
+                    t_e = time.perf_counter()
+                    if not timed:
+                        continue
+                    with lock:
+                        acc["units"] += r.stats["pair_iterations_total"]
+                        acc["latency"] += t_e - t_s
+                        acc["res"] = r
+                        if prof:
+                            acc["n_prof"] += 1
+                            acc["dom_ms"] += sum(r.stats["iter_kernel_ms"])
+                            acc["dom_bytes"] += sum(r.stats["iter_kernel_bytes"])
+                            acc["dom_n"] += sum(r.stats["iter_launches"])
+                            acc["s0_ms"] += r.stats["iter_kernel_ms"][0]
+                            acc["s0_bytes"] += r.stats["iter_kernel_bytes"][0]
+                            acc["first_ms"] += sum(r.stats["first_kernel_ms"])
+
+        if D == 1:
+            worker(0)
+        else:
+            th = [threading.Thread(target=worker, args=(k,)) for k in range(D)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+
+    # the dominant kernel = the steady-state iteration kernel (one template instantiation), ALL its launches of the
+    # event-bracketed steps at every pyramid scale -- the same set rocprofv3 --stats averages under that kernel's name
+    run_steps(max(args.warmup, D if D > 1 else 0), timed=False)
     barrier()
     t0 = time.perf_counter()
-    units = 0
-    # the dominant kernel = the steady-state iteration kernel (one template instantiation), ALL its launches of the
-    # timed steps at every pyramid scale -- the same set rocprofv3 --stats averages under that kernel's name
-    dom_ms = dom_bytes = 0.0
-    dom_n = 0
-    s0_ms = s0_bytes = 0.0
-    first_ms = 0.0
-    n_prof = 0
-    for i in range(args.steps):
-        eng.set_profiling(profiled(i))
-        res = eng.solve(I1, I2, prob, want_stats=True)
-        units += res.stats["pair_iterations_total"]
-        if not profiled(i):
-            continue
-        n_prof += 1
-        dom_ms += sum(res.stats["iter_kernel_ms"])
-        dom_bytes += sum(res.stats["iter_kernel_bytes"])
-        dom_n += sum(res.stats["iter_launches"])
-        s0_ms += res.stats["iter_kernel_ms"][0]
-        s0_bytes += res.stats["iter_kernel_bytes"][0]
-        first_ms += sum(res.stats["first_kernel_ms"])
+    run_steps(args.steps, timed=True)
     barrier()
     dt = time.perf_counter() - t0
+    units, res, n_prof = acc["units"], acc["res"], acc["n_prof"]
+    dom_ms, dom_bytes, dom_n = acc["dom_ms"], acc["dom_bytes"], acc["dom_n"]
+    s0_ms, s0_bytes, first_ms = acc["s0_ms"], acc["s0_bytes"], acc["first_ms"]
 
     # solution quality on this shard (not part of the timed region)
     n = eng.lib.ica_nparams(cfg["transform"])
@@ -170,7 +212,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": cfg["name"], "pairs_per_gpu": B, "height": H, "width": W, "channels": C,
                        "transform": tname, "robust_type": cfg["robust"], "nscales": cfg["nscales"], "tol": 1e-3,
-                       "delta": 10, "parallelism": f"{world} x independent pair shards (no collective)"},
+                       "delta": 10, "parallelism": f"{world} x independent pair shards (no collective)"
+                       + (f", {D} solves in flight per GPU" if D > 1 else ""), "in_flight": D},
+            "step_latency_ms": acc["latency"] / max(args.steps, 1) * 1e3,
             "image_pairs_per_s": pairs_all / dt,
             "pair_iterations_per_step": units_all / args.steps,
             "roofline": {
