@@ -129,6 +129,36 @@ def main():
         e.prepare(prob)
     streams = [None] if D == 1 else [torch.cuda.Stream(device=eng.device) for _ in range(D)]
     lock = threading.Lock()
+
+    class Gate:
+        """Event-bracketed steps run ALONE (the other in-flight solves pause around them), so that the kernel durations
+        they measure are those of the kernel, not of kernels sharing the GPU with another solve's."""
+
+        def __init__(self):
+            self.cv, self.active, self.excl, self.want_excl = threading.Condition(), 0, False, 0
+
+        def enter(self, exclusive):
+            with self.cv:
+                if exclusive:
+                    self.want_excl += 1
+                    while self.excl or self.active > 0:
+                        self.cv.wait()
+                    self.want_excl -= 1
+                    self.excl = True
+                else:
+                    while self.excl or self.want_excl > 0:
+                        self.cv.wait()
+                self.active += 1
+
+        def leave(self, exclusive):
+            with self.cv:
+                self.active -= 1
+                if exclusive:
+                    self.excl = False
+                self.cv.notify_all()
+
+    gate = Gate()
+    errors = []
     acc = dict(units=0, dom_ms=0.0, dom_bytes=0.0, dom_n=0, s0_ms=0.0, s0_bytes=0.0, first_ms=0.0, n_prof=0, res=None,
                latency=0.0)
 
@@ -145,10 +175,19 @@ def main():
                     if i is None:
                         return
                     prof = profiled(i) if timed else True
-                    engines[k].set_profiling(prof)
-                    t_s = time.perf_counter()
-                    r = engines[k].solve(I1, I2, prob, want_stats=True)
-                    t_e = time.perf_counter()
+                    alone = prof and timed and D > 1
+                    gate.enter(alone)
+                    try:
+                        engines[k].set_profiling(prof)
+                        t_s = time.perf_counter()
+                        r = engines[k].solve(I1, I2, prob, want_stats=True)
+                        t_e = time.perf_counter()
+                    except BaseException as exc:  # re-raised by the main thread after the join
+                        with lock:
+                            errors.append(exc)
+                        return
+                    finally:
+                        gate.leave(alone)
                     if not timed:
                         continue
                     with lock:
@@ -172,6 +211,8 @@ def main():
                 t.start()
             for t in th:
                 t.join()
+        if errors:
+            raise errors[0]
 
     # the dominant kernel = the steady-state iteration kernel (one template instantiation), ALL its launches of the
     # event-bracketed steps at every pyramid scale -- the same set rocprofv3 --stats averages under that kernel's name
