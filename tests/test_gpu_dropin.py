@@ -129,3 +129,21 @@ def test_transform_image_matches_bilinear_restatement(t, gt):
     # positions that fall within 1e-9 of an integer may pick a different (equally weighted) tap pair: exclude none,
     # the interpolant is continuous, so values still agree
     np.testing.assert_allclose(got, want, atol=5e-3)
+
+
+def test_bicubic_interpolation_module_matches_oracle_warp():
+    """bicubic_interpolation.bicubic_interpolation_skimage (reference :154-206): values, NaN mask and range clip."""
+    from inverse_compositional_algorithm_amd import bicubic_interpolation as bi
+    from inverse_compositional_algorithm_amd.transformation import TransformType
+    from inverse_compositional_algorithm_amd import synthetic as syn
+    _, I2, _ = syn.make_pair(77, 72, 88, 3, 5)
+    img = I2.astype(np.float64)
+    for t, p in ((TransformType.TRANSLATION, [2.3, -1.7]), (TransformType.EUCLIDEAN, [1.5, 0.5, 0.03]),
+                 (TransformType.HOMOGRAPHY, [0.01, 0.02, 1.5, -0.015, 0.01, -2.0, 1e-5, -2e-5]),
+                 (TransformType.AFFINITY, [0.0] * 6)):
+        got = bi.bicubic_interpolation_skimage(img, np.array(p), t, True, 10)
+        M = np.eye(3) if all(abs(v) < 1e-10 for v in p) else oc.params2matrix(np.array(p), t.value)
+        want = oc.keys_warp(img, M)
+        assert got.shape == want.shape and got.dtype == np.float64
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        np.testing.assert_allclose(np.nan_to_num(got), np.nan_to_num(want), atol=2e-3)
