@@ -309,7 +309,8 @@ struct SolveArgs {
 // lane k < 44 of group g adds tiles g, g+4, g+8, ... of accumulator k (4 loads in flight), then the 4 group sums are
 // added in group order.  Only accumulators [k_lo, k_hi) are touched.
 constexpr int kSolveThreads = 256;
-constexpr int kSolveScratch = 5 * kAccStride + 2 * kMaxN * kMaxN + kLuWork;  // doubles of LDS a solve needs
+// doubles of LDS a solve needs: s[44] | gather scratch | H | H^-1 | LU factors [64] + pivots [8] + one x[8] per column
+constexpr int kSolveScratch = 5 * kAccStride + 2 * kMaxN * kMaxN + kMaxN * kMaxN + kMaxN + kMaxN * kMaxN;
 __device__ __forceinline__ void gather_partials(const double* partials, int slot, int tiles, double* s /*LDS[44]*/,
                                                 double* part /*LDS[4][44], or [32][8] for the b-only case*/,
                                                 int k_lo = 0, int k_hi = kAccStride) {
@@ -388,17 +389,36 @@ __device__ __forceinline__ void solve_pair(const SolveArgs& a, int slot, int pai
   double* Hi = Hm + kMaxN * kMaxN;
   double* ws = Hi + kMaxN * kMaxN;
   gather_partials(a.partials, slot, a.tiles, s, scratch + kAccStride, 0, a.invert_h ? kAccStride : kMaxN);
-  if (threadIdx.x != 0) return;
   const int n = a.n;
   const double* hinv = a.Hinv + (size_t)pair * 64;
   if (a.invert_h) {
-    for (int k = 0; k < n; ++k)
-      for (int m = k; m < n; ++m) Hm[k * kMaxN + m] = Hm[m * kMaxN + k] = s[kMaxN + tri_index(k, m, n)];
-    lu_inverse(n, Hm, Hi, kMaxN, ws);  // derivatives.py:110-130 (zeros if singular)
+    // inv(H) like np.linalg.inv (derivatives.py:110-130; zeros if singular): thread 0 factorises, then the n columns
+    // of the inverse are solved by n threads (same arithmetic per column as the serial lu_inverse)
+    double* fa = ws;                       // [n][kMaxN] factors
+    double* pivd = fa + kMaxN * kMaxN;     // [kMaxN]
+    double* xs = pivd + kMaxN;             // [n][kMaxN] per-column scratch
+    if (threadIdx.x == 0) {
+      for (int k = 0; k < n; ++k)
+        for (int m = k; m < n; ++m) Hm[k * kMaxN + m] = Hm[m * kMaxN + k] = s[kMaxN + tri_index(k, m, n)];
+      pivd[kMaxN - 1] = 0.0;
+      const bool ok = lu_factor(n, Hm, kMaxN, fa, pivd);
+      Hm[kMaxN * kMaxN - 1] = ok ? 1.0 : 0.0;  // (n <= 8: for n == 8 the last entry of H has been consumed by now)
+    }
+    __syncthreads();
+    const bool ok = Hm[kMaxN * kMaxN - 1] != 0.0;
+    if ((int)threadIdx.x < n) {
+      if (ok) {
+        lu_inverse_column(n, fa, pivd, threadIdx.x, xs + threadIdx.x * kMaxN, Hi, kMaxN);
+      } else {
+        for (int i = 0; i < n; ++i) Hi[i * kMaxN + threadIdx.x] = 0.0;
+      }
+    }
+    __syncthreads();
     hinv = Hi;
-    if (a.store_hinv)
-      for (int i = 0; i < kMaxN * kMaxN; ++i) a.Hinv[(size_t)pair * 64 + i] = Hi[i];
   }
+  if (threadIdx.x != 0) return;
+  if (a.invert_h && a.store_hinv)
+    for (int i = 0; i < kMaxN * kMaxN; ++i) a.Hinv[(size_t)pair * 64 + i] = Hi[i];
   double dp[kMaxN], e2 = 0.0;
   for (int i = 0; i < n; ++i) {  // image_optimisation.py:146-155
     double v = 0.0;

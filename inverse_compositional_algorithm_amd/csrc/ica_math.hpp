@@ -162,10 +162,11 @@ __host__ __device__ inline void zoom_in_parameters(double* p, int tt, int w, int
 // `ws` is a caller-provided workspace of kLuWork doubles (LDS in the kernels: private arrays with run-time
 // indices would live in scratch memory).
 constexpr int kLuWork = kMaxN * kMaxN + 2 * kMaxN;
-__host__ __device__ inline bool lu_inverse(int n, const double* H, double* Hinv, int ld, double* ws) {
-  double* a = ws;                        // [n][kMaxN]
-  double* x = ws + kMaxN * kMaxN;        // [kMaxN]
-  double* pivd = x + kMaxN;              // [kMaxN] pivot rows (stored as doubles: exact small integers)
+
+// LU with partial pivoting of the n x n matrix H (row stride ld) into a[n][kMaxN] (unit-lower L below the
+// diagonal, U on and above it) and the pivot rows pivd[kMaxN] (stored as doubles: exact small integers).
+// False when a pivot is exactly zero (LAPACK's "singular").
+__host__ __device__ inline bool lu_factor(int n, const double* H, int ld, double* a, double* pivd) {
   for (int i = 0; i < n; ++i)
     for (int j = 0; j < n; ++j) a[i * kMaxN + j] = H[i * ld + j];
   bool ok = true;
@@ -187,29 +188,41 @@ __host__ __device__ inline bool lu_inverse(int n, const double* H, double* Hinv,
       for (int j = k + 1; j < n; ++j) a[i * kMaxN + j] -= l * a[k * kMaxN + j];
     }
   }
-  if (!ok) {
+  return ok;
+}
+
+// Column c of the inverse from the factors: solve L U x = P e_c; x is a caller-provided scratch of kMaxN doubles.
+// The columns are independent of each other (the kernels give one to each of n threads).
+__host__ __device__ inline void lu_inverse_column(int n, const double* a, const double* pivd, int c, double* x,
+                                                  double* Hinv, int ld) {
+  for (int i = 0; i < n; ++i) x[i] = (i == c) ? 1.0 : 0.0;
+  for (int k = 0; k < n; ++k) {
+    const int pk = (int)pivd[k];
+    if (pk != k) { const double t = x[k]; x[k] = x[pk]; x[pk] = t; }
+  }
+  for (int i = 1; i < n; ++i) {  // L y = P e_c (unit lower)
+    double sum = x[i];
+    for (int j = 0; j < i; ++j) sum -= a[i * kMaxN + j] * x[j];
+    x[i] = sum;
+  }
+  for (int i = n - 1; i >= 0; --i) {  // U x = y
+    double sum = x[i];
+    for (int j = i + 1; j < n; ++j) sum -= a[i * kMaxN + j] * x[j];
+    x[i] = sum / a[i * kMaxN + i];
+  }
+  for (int i = 0; i < n; ++i) Hinv[i * ld + c] = x[i];
+}
+
+__host__ __device__ inline bool lu_inverse(int n, const double* H, double* Hinv, int ld, double* ws) {
+  double* a = ws;                        // [n][kMaxN]
+  double* x = ws + kMaxN * kMaxN;        // [kMaxN]
+  double* pivd = x + kMaxN;              // [kMaxN]
+  if (!lu_factor(n, H, ld, a, pivd)) {
     for (int i = 0; i < n; ++i)
       for (int j = 0; j < n; ++j) Hinv[i * ld + j] = 0.0;
     return false;
   }
-  for (int c = 0; c < n; ++c) {
-    for (int i = 0; i < n; ++i) x[i] = (i == c) ? 1.0 : 0.0;
-    for (int k = 0; k < n; ++k) {
-      const int pk = (int)pivd[k];
-      if (pk != k) { const double t = x[k]; x[k] = x[pk]; x[pk] = t; }
-    }
-    for (int i = 1; i < n; ++i) {  // L y = P e_c (unit lower)
-      double sum = x[i];
-      for (int j = 0; j < i; ++j) sum -= a[i * kMaxN + j] * x[j];
-      x[i] = sum;
-    }
-    for (int i = n - 1; i >= 0; --i) {  // U x = y
-      double sum = x[i];
-      for (int j = i + 1; j < n; ++j) sum -= a[i * kMaxN + j] * x[j];
-      x[i] = sum / a[i * kMaxN + i];
-    }
-    for (int i = 0; i < n; ++i) Hinv[i * ld + c] = x[i];
-  }
+  for (int c = 0; c < n; ++c) lu_inverse_column(n, a, pivd, c, x, Hinv, ld);
   return true;
 }
 
