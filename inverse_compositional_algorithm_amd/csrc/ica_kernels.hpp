@@ -381,6 +381,39 @@ __global__ __launch_bounds__(kSolveThreads) void ica_setup_solve_kernel(const do
   }
 }
 
+// lu_factor() of ica_math.hpp with the row operations of each elimination step spread over the lanes of ONE wave
+// (lane i owns row i; same arithmetic per element, so the factors are bit-identical to the serial ones).  Called by
+// a whole wave; `a` and `pivd` are LDS.  LDS operations of a wave complete in program order, and every lane runs
+// the same instruction stream, so a lane reads what other lanes stored in an earlier statement.
+__device__ __forceinline__ bool lu_factor_wave(int n, const double* H, int ld, double* a, double* pivd, int lane) {
+  if (lane < n)
+    for (int j = 0; j < n; ++j) a[lane * kMaxN + j] = H[lane * ld + j];
+  bool ok = true;
+  for (int k = 0; k < n; ++k) {
+    int pr = k;  // every lane finds the pivot itself (same answer, no broadcast needed)
+    double best = fabs(a[k * kMaxN + k]);
+    for (int i = k + 1; i < n; ++i) {
+      const double v = fabs(a[i * kMaxN + k]);
+      if (v > best) { best = v; pr = i; }
+    }
+    if (lane == 0) pivd[k] = (double)pr;
+    if (pr != k && lane < n) {  // lane j swaps column j of the two rows
+      const double t = a[k * kMaxN + lane];
+      a[k * kMaxN + lane] = a[pr * kMaxN + lane];
+      a[pr * kMaxN + lane] = t;
+    }
+    const double piv = a[k * kMaxN + k];
+    if (piv == 0.0) { ok = false; continue; }
+    const double r = 1.0 / piv;
+    if (lane > k && lane < n) {
+      const double l = a[lane * kMaxN + k] * r;
+      a[lane * kMaxN + k] = l;
+      for (int j = k + 1; j < n; ++j) a[lane * kMaxN + j] -= l * a[k * kMaxN + j];
+    }
+  }
+  return ok;
+}
+
 // Solve + compositional update + loop control for one active pair (ref :117-131 / :233-259).  Called by all 256
 // threads of a workgroup; `scratch` is kSolveScratch doubles of LDS.  `slot` indexes the launch's partials.
 __device__ __forceinline__ void solve_pair(const SolveArgs& a, int slot, int pair, double* scratch) {
@@ -392,17 +425,18 @@ __device__ __forceinline__ void solve_pair(const SolveArgs& a, int slot, int pai
   const int n = a.n;
   const double* hinv = a.Hinv + (size_t)pair * 64;
   if (a.invert_h) {
-    // inv(H) like np.linalg.inv (derivatives.py:110-130; zeros if singular): thread 0 factorises, then the n columns
-    // of the inverse are solved by n threads (same arithmetic per column as the serial lu_inverse)
+    // inv(H) like np.linalg.inv (derivatives.py:110-130; zeros if singular): wave 0 factorises (one lane per row), then
+    // the n columns of the inverse are solved by n threads (same arithmetic per element as the serial lu_inverse)
     double* fa = ws;                       // [n][kMaxN] factors
     double* pivd = fa + kMaxN * kMaxN;     // [kMaxN]
     double* xs = pivd + kMaxN;             // [n][kMaxN] per-column scratch
-    if (threadIdx.x == 0) {
-      for (int k = 0; k < n; ++k)
-        for (int m = k; m < n; ++m) Hm[k * kMaxN + m] = Hm[m * kMaxN + k] = s[kMaxN + tri_index(k, m, n)];
-      pivd[kMaxN - 1] = 0.0;
-      const bool ok = lu_factor(n, Hm, kMaxN, fa, pivd);
-      Hm[kMaxN * kMaxN - 1] = ok ? 1.0 : 0.0;  // (n <= 8: for n == 8 the last entry of H has been consumed by now)
+    if (threadIdx.x < 64) {  // wave 0: expand the packed upper triangle, then factorise with one lane per row
+      const int k = threadIdx.x >> 3, m = threadIdx.x & 7;
+      if (k < n && m < n) Hm[k * kMaxN + m] = s[kMaxN + (k <= m ? tri_index(k, m, n) : tri_index(m, k, n))];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const bool okf = lu_factor_wave(n, Hm, kMaxN, fa, pivd, threadIdx.x);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (threadIdx.x == 0) Hm[kMaxN * kMaxN - 1] = okf ? 1.0 : 0.0;  // (H has been copied into the factors by now)
     }
     __syncthreads();
     const bool ok = Hm[kMaxN * kMaxN - 1] != 0.0;
