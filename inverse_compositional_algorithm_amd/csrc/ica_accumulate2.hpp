@@ -147,9 +147,9 @@ __global__ __launch_bounds__(kBlock) void ica_accumulate2_kernel(LevelArgs a, So
   if (a.act_list) {
     // tell the host how many pairs entered this iteration (it sizes the next launch from it, without a sync)
     if (a.host_slot && blockIdx.x == 0 && threadIdx.x == 0)
-      __hip_atomic_store(a.host_slot, *a.act_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (pair_slot >= *a.act_count) return;
-    pair = a.act_list[pair_slot];
+      __hip_atomic_store(a.host_slot, list_total(a.act_count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (pair_slot >= list_total(a.act_count)) return;
+    pair = list_entry(a.act_list, a.act_count, a.list_cap, pair_slot);
   } else if (pair_slot >= a.n_pairs) {
     return;
   }
@@ -598,8 +598,8 @@ __global__ __launch_bounds__(kBlock) void ica_accumulate2_kernel(LevelArgs a, So
   if constexpr (kB) {
     if (sa.tickets) {
       if (blockIdx.x == 0 && threadIdx.x == 0) {
-        *sa.clr_count = 0;
-        if (sa.count_hist) sa.count_hist[sa.level * sa.max_iter + sa.iter] = *sa.cur_count;
+        list_clear(sa.clr_count);
+        if (sa.count_hist) sa.count_hist[sa.level * sa.max_iter + sa.iter] = list_total(sa.cur_count);
       }
       int* flag = reinterpret_cast<int*>(lds);  // (the fold scratch is dead after the barrier below)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -70,7 +70,7 @@ struct ica_ctx {
   DevBuf tmp_resample;                                // intermediate of the separable pyramid pass
   DevBuf partials, hinv, p_prev, lambda_it, error, niter, lists, counts, count_hist, minmax, mm_part, mm_in, tickets;
   DevBuf scratch_p;
-  int* pinned_count = nullptr;   // 4 ints for synchronous reads + a [scales][max_iter] board the kernels post to
+  int* pinned_count = nullptr;   // one list's shard counters for synchronous reads + a [scales][max_iter] board the kernels post to
   int* board = nullptr;          // host pointer of the board (pinned, host-coherent)
   int* board_dev = nullptr;      // device pointer of the same memory
   size_t board_cap = 0;
@@ -353,8 +353,8 @@ int ensure_state(ica_ctx* ctx, const ica_problem* pr, const LevelGeom* g) {
   ICA_HIP(ctx, ctx->lambda_it.ensure(B * sizeof(double)));
   ICA_HIP(ctx, ctx->error.ensure(B * sizeof(double)));
   ICA_HIP(ctx, ctx->niter.ensure(B * sizeof(int)));
-  ICA_HIP(ctx, ctx->lists.ensure(3 * B * sizeof(int)));
-  ICA_HIP(ctx, ctx->counts.ensure(4 * sizeof(int)));
+  ICA_HIP(ctx, ctx->lists.ensure(3 * (size_t)kListShards * list_shard_cap((int)B) * sizeof(int)));
+  ICA_HIP(ctx, ctx->counts.ensure(3 * kListShards * kShardStride * sizeof(int)));
   ICA_HIP(ctx, ctx->tickets.ensure(B * sizeof(int)));
   ICA_HIP(ctx, ctx->count_hist.ensure((size_t)pr->nscales * std::max(1, pr->max_iter) * sizeof(int)));
   ICA_HIP(ctx, ctx->minmax.ensure((size_t)pr->nscales * B * 2 * sizeof(float)));
@@ -369,7 +369,7 @@ int ensure_state(ica_ctx* ctx, const ica_problem* pr, const LevelGeom* g) {
   }
   if (pr->nscales > 1)
     ICA_HIP(ctx, ctx->tmp_resample.ensure(B * pr->channels * g[1].H * g[0].W * sizeof(float)));
-  if (!ctx->pinned_count) ICA_HIP(ctx, hipHostMalloc((void**)&ctx->pinned_count, 4 * sizeof(int), hipHostMallocDefault));
+  if (!ctx->pinned_count) ICA_HIP(ctx, hipHostMalloc((void**)&ctx->pinned_count, kListShards * kShardStride * sizeof(int), hipHostMallocDefault));
   const size_t need = (size_t)pr->nscales * std::max(1, pr->max_iter);
   if (need > ctx->board_cap) {
     if (ctx->board) { ICA_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipHostFree(ctx->board); ctx->board = nullptr; }
@@ -513,6 +513,8 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
 
   int* lists = ctx->lists.as<int>();
   int* counts = ctx->counts.as<int>();
+  const int list_cap = list_shard_cap(B);                       // three sharded lists (ica_kernels.hpp)
+  const size_t list_stride = (size_t)kListShards * list_cap, cnt_stride = (size_t)kListShards * kShardStride;
   struct EvRec { int level; size_t e0, e1; bool first; };
   std::vector<EvRec> evrecs;
   size_t ev_used = 0;
@@ -568,9 +570,11 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
         int v = *slot, spins = 0;
         while (v < 0 && spins < 200000000) { v = *slot; ++spins; }
         if (v < 0) {  // should not happen: fall back to a synchronous read
-          ICA_HIP(ctx, hipMemcpyAsync(ctx->pinned_count, counts + cur, sizeof(int), hipMemcpyDeviceToHost, st));
+          ICA_HIP(ctx, hipMemcpyAsync(ctx->pinned_count, counts + (size_t)cur * kListShards * kShardStride,
+                                      kListShards * kShardStride * sizeof(int), hipMemcpyDeviceToHost, st));
           ICA_HIP(ctx, hipStreamSynchronize(st));
-          v = ctx->pinned_count[0];
+          v = 0;
+          for (int sh = 0; sh < kListShards; ++sh) v += ctx->pinned_count[sh * kShardStride];
         }
         nb = std::min(nb, v);
         if (nb == 0) break;
@@ -578,8 +582,9 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
       la.host_slot = ctx->board_dev + (size_t)s * max_iter + it;
       set_tiling(lg, nb);  // accumulate and solve of one iteration always agree on the tiling
       la.tiles_x = lg.tiles_x; la.tiles_y = lg.tiles_y; la.tile_h = lg.tile_h;
-      la.act_list = lists + (size_t)cur * B;
-      la.act_count = counts + cur;
+      la.act_list = lists + (size_t)cur * list_stride;
+      la.act_count = counts + (size_t)cur * cnt_stride;
+      la.list_cap = list_cap;
       size_t e0 = 0, e1 = 0;
       if (ctx->profiling) {
         ICA_TRY(next_event(&e0));
@@ -591,8 +596,9 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
       sa.lambdaN = pr->lambdaN; sa.lambda_ratio = pr->lambda_ratio;
       sa.partials = la.partials; sa.p = p; sa.p_prev = ctx->p_prev.as<double>(); sa.Hinv = ctx->hinv.as<double>();
       sa.lambda_it = ctx->lambda_it.as<double>(); sa.error = ctx->error.as<double>(); sa.niter = ctx->niter.as<int>();
-      sa.cur_list = lists + (size_t)cur * B; sa.cur_count = counts + cur;
-      sa.nxt_list = lists + (size_t)nxt * B; sa.nxt_count = counts + nxt; sa.clr_count = counts + clr;
+      sa.cur_list = lists + (size_t)cur * list_stride; sa.cur_count = counts + (size_t)cur * cnt_stride;
+      sa.nxt_list = lists + (size_t)nxt * list_stride; sa.nxt_count = counts + (size_t)nxt * cnt_stride;
+      sa.clr_count = counts + (size_t)clr * cnt_stride; sa.list_cap = list_cap;
       sa.count_hist = ctx->count_hist.as<int>(); sa.trace = trace_out;
       const bool first_l2 = l2_fold_hessian && it == 0;
       sa.invert_h = robust || first_l2;  // the solve inverts the H it receives ...

@@ -31,11 +31,48 @@ struct LevelArgs {
   const double* lambda_it;  // [B]
   const float* minmax;      // [B][2] clip range of I2 at this level
   const int* act_list;      // current active pairs (nullptr: pair index = slot)
-  const int* act_count;
+  const int* act_count;   // kListShards shard counters (see list_total / list_entry)
+  int list_cap;           // entries per shard
   int n_pairs;              // pairs covered by this launch (bound when act_list == nullptr)
   int* host_slot;           // nullable, host-visible: receives *act_count (pairs entering this iteration)
   double* partials;         // [slot][tiles][kAccStride]; slot = index into the active list (= pair without a list)
 };
+
+// ---- active-pair lists ------------------------------------------------------------------------------
+// A list of the pairs that enter an iteration is kept in kListShards shards; a producer (the solve of workgroup /
+// slot b) appends to shard b & 7 with an atomicAdd on THAT shard's counter.  1024 workgroups adding to one counter
+// serialise on it (measured: +7.5 us per solve launch); eight counters on eight cache lines do not.  A shard never
+// receives more than ceil(B / 8) entries, so the eight shards together are no larger than one flat list.
+// Consumers number the entries shard after shard.
+constexpr int kListShards = 8;
+constexpr int kShardStride = 32;  // ints between two shard counters: one 128-byte line each
+__host__ __device__ inline int list_shard_cap(int batch) { return (batch + kListShards - 1) / kListShards; }
+__device__ __forceinline__ int list_total(const int* cnt) {
+  int t = 0;
+#pragma unroll
+  for (int s = 0; s < kListShards; ++s) t += cnt[s * kShardStride];
+  return t;
+}
+// entry number `slot` of the list (caller has checked slot < list_total)
+__device__ __forceinline__ int list_entry(const int* list, const int* cnt, int cap, int slot) {
+  int shard = 0;
+#pragma unroll
+  for (int s = 0; s < kListShards - 1; ++s) {
+    const int c = cnt[s * kShardStride];
+    if (shard == s && slot >= c) { slot -= c; shard = s + 1; }
+  }
+  return list[shard * cap + slot];
+}
+__device__ __forceinline__ void list_append(int* list, int* cnt, int cap, int producer, int value) {
+  const int shard = producer & (kListShards - 1);
+  const int idx = atomicAdd(cnt + shard * kShardStride, 1);
+  list[shard * cap + idx] = value;
+}
+__device__ __forceinline__ void list_clear(int* cnt) {
+#pragma unroll
+  for (int s = 0; s < kListShards; ++s) cnt[s * kShardStride] = 0;
+}
+
 
 template <int TT> struct NP;
 template <> struct NP<ICA_TRANSLATION> { static constexpr int n = 2; };
@@ -141,9 +178,9 @@ __global__ __launch_bounds__(kBlock) void ica_accumulate_kernel(LevelArgs a) {
   int pair = blockIdx.y;
   if (a.act_list) {
     if (a.host_slot && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
-      __hip_atomic_store(a.host_slot, *a.act_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if ((int)blockIdx.y >= *a.act_count) return;
-    pair = a.act_list[blockIdx.y];
+      __hip_atomic_store(a.host_slot, list_total(a.act_count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if ((int)blockIdx.y >= list_total(a.act_count)) return;
+    pair = list_entry(a.act_list, a.act_count, a.list_cap, blockIdx.y);
   }
   const int tile = blockIdx.x;
   const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
@@ -298,6 +335,7 @@ struct SolveArgs {
   const int* cur_list; const int* cur_count;
   int* nxt_list; int* nxt_count;
   int* clr_count;
+  int list_cap;  // entries per list shard
   int* count_hist;        // [nscales][max_iter]
   double* trace;          // nullable [B][nscales][max_iter][10]
   int invert_h;           // this launch carries H partials: invert them (robust loop; L2: first iteration of a level)
@@ -481,19 +519,18 @@ __device__ __forceinline__ void solve_pair(const SolveArgs& a, int slot, int pai
   a.error[pair] = err;
   a.niter[pair] = it + 1;
   if (err > a.tol && it + 1 < a.max_iter) {  // ref :109 / :225
-    const int idx = atomicAdd(a.nxt_count, 1);
-    a.nxt_list[idx] = pair;
+    list_append(a.nxt_list, a.nxt_count, a.list_cap, slot, pair);
   }
 }
 
 __global__ __launch_bounds__(kSolveThreads) void ica_solve_kernel(SolveArgs a) {
   __shared__ double scratch[kSolveScratch];
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    *a.clr_count = 0;
-    if (a.count_hist) a.count_hist[a.level * a.max_iter + a.iter] = *a.cur_count;
+    list_clear(a.clr_count);
+    if (a.count_hist) a.count_hist[a.level * a.max_iter + a.iter] = list_total(a.cur_count);
   }
-  if ((int)blockIdx.x >= *a.cur_count) return;
-  solve_pair(a, blockIdx.x, a.cur_list[blockIdx.x], scratch);
+  if ((int)blockIdx.x >= list_total(a.cur_count)) return;
+  solve_pair(a, blockIdx.x, list_entry(a.cur_list, a.cur_count, a.list_cap, blockIdx.x), scratch);
 }
 
 struct LevelInitArgs {
@@ -505,14 +542,17 @@ struct LevelInitArgs {
   double* error;
   int* niter;
   int* niter_out;      // [B][nscales]: receives the finished (level+1) counts
-  int* list0; int* counts;  // counts[3]
+  int* list0; int* counts;  // 3 lists x kListShards shard counters
 };
 
 // Start of a level (ref :106-107, :221-223, :327,:337,:371-372): p from the coarser level through
 // zoom_in_parameters (or zeros / the caller's p at the coarsest level), iteration state reset.
 __global__ void ica_level_init_kernel(LevelInitArgs a) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b == 0) { a.counts[0] = a.batch; a.counts[1] = 0; a.counts[2] = 0; }
+  if (b < 3 * kListShards) {  // list 0 = all pairs (pair i in shard i & 7), lists 1 and 2 empty
+    const int l = b / kListShards, sh = b % kListShards;
+    a.counts[(l * kListShards + sh) * kShardStride] = l == 0 ? (a.batch - sh + kListShards - 1) / kListShards : 0;
+  }
   if (b >= a.batch) return;
   double* p = a.p + (size_t)b * 8;
   if (a.level == a.nscales - 1) {
@@ -527,7 +567,7 @@ __global__ void ica_level_init_kernel(LevelInitArgs a) {
   a.lambda_it[b] = a.lambda_user > 0.0 ? a.lambda_user : a.lambda0;
   a.error[b] = 1e10;
   a.niter[b] = 0;
-  a.list0[b] = b;
+  a.list0[(b & (kListShards - 1)) * list_shard_cap(a.batch) + (b >> 3)] = b;
 }
 
 __global__ void ica_finish_kernel(int batch, int nscales, const int* niter, const double* error, int* niter_out,
