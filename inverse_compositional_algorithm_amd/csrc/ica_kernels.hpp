@@ -459,9 +459,16 @@ __device__ __forceinline__ void solve_pair(const SolveArgs& a, int slot, int pai
   double* Hm = scratch + 5 * kAccStride;
   double* Hi = Hm + kMaxN * kMaxN;
   double* ws = Hi + kMaxN * kMaxN;
+  // the stored inverse (L2, iterations >= 1) is fetched while the partials are being gathered
+  double hpre = 0.0;
+  if (!a.invert_h && threadIdx.x < kMaxN * kMaxN) hpre = a.Hinv[(size_t)pair * 64 + threadIdx.x];
   gather_partials(a.partials, slot, a.tiles, s, scratch + kAccStride, 0, a.invert_h ? kAccStride : kMaxN);
   const int n = a.n;
-  const double* hinv = a.Hinv + (size_t)pair * 64;
+  const double* hinv = Hi;
+  if (!a.invert_h) {
+    if (threadIdx.x < kMaxN * kMaxN) Hi[threadIdx.x] = hpre;
+    __syncthreads();
+  }
   if (a.invert_h) {
     // inv(H) like np.linalg.inv (derivatives.py:110-130; zeros if singular): wave 0 factorises (one lane per row), then
     // the n columns of the inverse are solved by n threads (same arithmetic per element as the serial lu_inverse)
@@ -486,7 +493,6 @@ __device__ __forceinline__ void solve_pair(const SolveArgs& a, int slot, int pai
       }
     }
     __syncthreads();
-    hinv = Hi;
   }
   if (threadIdx.x != 0) return;
   if (a.invert_h && a.store_hinv)
