@@ -139,9 +139,13 @@ __global__ __launch_bounds__(kBlock) void ica_accumulate2_kernel(LevelArgs a, So
   // an L2), so consecutive block ids take different PAIRS and the blocks that share an XCD walk through the tiles
   // of the same pair: tile halos and the rows two chunks share are then served by that XCD's L2.  (Placement is a
   // speed matter only; nothing depends on it for correctness.)
+  // With few pairs in the launch that map leaves XCDs idle or unevenly loaded (a single straggler pair would run on
+  // one eighth of the chip): then the tiles of a pair are simply dealt to consecutive workgroups, i.e. round-robin
+  // over all XCDs (those launches are latency-bound, not traffic-bound).
   const int ntiles = a.tiles_x * a.tiles_y;
-  const int slot = blockIdx.x >> 3, xcd = blockIdx.x & 7;
-  const int pair_slot = (slot / ntiles) * 8 + xcd;
+  const bool flat = a.n_pairs < kFlatMapBelow;
+  const int slot = flat ? (int)blockIdx.x : (int)(blockIdx.x >> 3), xcd = blockIdx.x & 7;
+  const int pair_slot = flat ? slot / ntiles : (slot / ntiles) * 8 + xcd;
   const int tile_id = slot - (slot / ntiles) * ntiles;
   int pair = pair_slot;
   if (a.act_list) {

@@ -289,12 +289,15 @@ void launch_accumulate_c(int C, dim3 grid, hipStream_t st, const LevelArgs& a, c
     else
       hipLaunchKernelGGL((ica_accumulate_kernel<TT, MODE, 3>), grid, dim3(kBlock), 0, st, a);
   } else {
-    // 1-D grid: (pairs rounded up to a multiple of 8) x tiles, decoded XCD-aware inside the kernel
-    const dim3 g1((unsigned)(((grid.y + 7) / 8) * 8 * grid.x));
+    // 1-D grid: (pairs rounded up to a multiple of 8) x tiles, decoded XCD-aware inside the kernel; launches of fewer
+    // than kFlatMapBelow pairs (a.n_pairs = pairs of the launch) use a flat pairs x tiles grid instead
+    const dim3 g1((unsigned)((int)grid.y < kFlatMapBelow ? grid.y * grid.x : ((grid.y + 7) / 8) * 8 * grid.x));
+    LevelArgs al = a;
+    al.n_pairs = (int)grid.y;  // the kernel picks the same map from it
     if (C == 1)
-      hipLaunchKernelGGL((ica_accumulate2_kernel<TT, MODE, 1>), g1, dim3(kBlock), 0, st, a, sa);
+      hipLaunchKernelGGL((ica_accumulate2_kernel<TT, MODE, 1>), g1, dim3(kBlock), 0, st, al, sa);
     else
-      hipLaunchKernelGGL((ica_accumulate2_kernel<TT, MODE, 3>), g1, dim3(kBlock), 0, st, a, sa);
+      hipLaunchKernelGGL((ica_accumulate2_kernel<TT, MODE, 3>), g1, dim3(kBlock), 0, st, al, sa);
   }
 }
 

@@ -20,6 +20,10 @@ constexpr int kFlush = 8;     // fp32 partial sums are promoted to fp64 every kF
 
 enum Mode { kModeL2 = 0, kModeRobust = 1, kModeHessian = 2 };
 
+#ifndef ICA_FLAT_BELOW
+#define ICA_FLAT_BELOW 8
+#endif
+
 struct LevelArgs {
   const float* I1;
   const float* I2;
@@ -33,7 +37,7 @@ struct LevelArgs {
   const int* act_list;      // current active pairs (nullptr: pair index = slot)
   const int* act_count;   // kListShards shard counters (see list_total / list_entry)
   int list_cap;           // entries per shard
-  int n_pairs;              // pairs covered by this launch (bound when act_list == nullptr)
+  int n_pairs;              // pairs covered by this launch (the bound when act_list == nullptr; picks the block map)
   int* host_slot;           // nullable, host-visible: receives *act_count (pairs entering this iteration)
   double* partials;         // [slot][tiles][kAccStride]; slot = index into the active list (= pair without a list)
 };
@@ -44,6 +48,7 @@ struct LevelArgs {
 // serialise on it (measured: +7.5 us per solve launch); eight counters on eight cache lines do not.  A shard never
 // receives more than ceil(B / 8) entries, so the eight shards together are no larger than one flat list.
 // Consumers number the entries shard after shard.
+constexpr int kFlatMapBelow = ICA_FLAT_BELOW;  // launches of fewer pairs use the flat block map (ica_accumulate2.hpp)
 constexpr int kListShards = 8;
 constexpr int kShardStride = 32;  // ints between two shard counters: one 128-byte line each
 __host__ __device__ inline int list_shard_cap(int batch) { return (batch + kListShards - 1) / kListShards; }
