@@ -223,7 +223,7 @@ int launch_minmax(ica_ctx* ctx, int batch, size_t elems, const float* img, float
   ICA_HIP(ctx, ctx->mm_part.ensure((size_t)batch * chunks * 2 * sizeof(float)));
   hipLaunchKernelGGL(ica_minmax_partial_kernel, dim3(chunks, batch), dim3(kBlock), 0, ctx->stream, img, elems, chunks,
                      ctx->mm_part.as<float>());
-  hipLaunchKernelGGL(ica_minmax_final_kernel, dim3((batch + 255) / 256), dim3(256), 0, ctx->stream,
+  hipLaunchKernelGGL(ica_minmax_final_kernel, dim3((batch + kWaves - 1) / kWaves), dim3(kBlock), 0, ctx->stream,
                      ctx->mm_part.as<float>(), chunks, batch, out);
   ICA_HIP(ctx, hipGetLastError());
   return ICA_OK;
@@ -262,7 +262,7 @@ int launch_pyramid_down(ica_ctx* ctx, int batch, int C, int H, int W, int h, int
                        part ? part + (size_t)p0 * vgroups * xblocks * 2 : nullptr);
   }
   if (part)
-    hipLaunchKernelGGL(ica_minmax_final_kernel, dim3((batch + 255) / 256), dim3(256), 0, ctx->stream, part, per_pair, batch,
+    hipLaunchKernelGGL(ica_minmax_final_kernel, dim3((batch + kWaves - 1) / kWaves), dim3(kBlock), 0, ctx->stream, part, per_pair, batch,
                        mm_out);
   for (int p0 = 0; p0 < planes; p0 += step) {
     const int np = std::min(step, planes - p0);

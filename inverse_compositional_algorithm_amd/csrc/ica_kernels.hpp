@@ -680,16 +680,27 @@ __global__ __launch_bounds__(kBlock) void ica_minmax_partial_kernel(const float*
   }
 }
 
-__global__ void ica_minmax_final_kernel(const float* __restrict__ part, int chunks, int batch, float* __restrict__ out) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= batch) return;
+// One wave per pair: the lanes stride over the pair's partials (coalesced), then a wave reduction.
+__global__ __launch_bounds__(kBlock) void ica_minmax_final_kernel(const float* __restrict__ part, int chunks, int batch,
+                                                                  float* __restrict__ out) {
+  const int b = blockIdx.x * kWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (b >= batch) return;  // whole wave
+  const float2* q = reinterpret_cast<const float2*>(part) + (size_t)b * chunks;
   float lo = INFINITY, hi = -INFINITY;
-  for (int c = 0; c < chunks; ++c) {
-    lo = fminf(lo, part[((size_t)b * chunks + c) * 2]);
-    hi = fmaxf(hi, part[((size_t)b * chunks + c) * 2 + 1]);
+  for (int c = lane; c < chunks; c += 64) {
+    const float2 v = q[c];
+    lo = fminf(lo, v.x);
+    hi = fmaxf(hi, v.y);
   }
-  out[b * 2] = lo;
-  out[b * 2 + 1] = hi;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    lo = fminf(lo, __shfl_down(lo, off, 64));
+    hi = fmaxf(hi, __shfl_down(hi, off, 64));
+  }
+  if (lane == 0) {
+    out[b * 2] = lo;
+    out[b * 2 + 1] = hi;
+  }
 }
 
 // ---- per-operator hooks -----------------------------------------------------------------------------
