@@ -88,8 +88,9 @@ typedef struct ica_problem {
 
 /* Filled by ica_solve_batch*_ when stats != NULL (the call then synchronises).
  * The iteration work of a scale is split by the kernel that did it: `iter_*` is the steady-state kernel
- * (L2: ica_accumulate2_kernel<TT, b-only, C>, iterations >= 1; robust: <TT, H+b, C>, every iteration), `first_*` is the
- * L2 path's first iteration of a level, which also accumulates the Hessian (<TT, H+b, C>; zeros for robust). */
+ * (L2: ica_accumulate2_kernel<TT, b-only, C>, iterations >= 1; robust: <TT, weighted H+b, C>, every iteration), `first_*`
+ * is the L2 path's first iteration of a level, which also accumulates the Hessian (<TT, unweighted H+b, C>; zeros for
+ * robust). */
 typedef struct ica_stats {
   int64_t pair_iterations[ICA_MAX_SCALES]; /* executed (pair, iteration) units per scale (0 = finest) */
   int64_t pair_iterations_total;

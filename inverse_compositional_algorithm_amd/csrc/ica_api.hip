@@ -317,6 +317,8 @@ void launch_accumulate_mode(int mode, int tt, int C, dim3 grid, hipStream_t st, 
                             const SolveArgs& sa = SolveArgs{}) {
   if (mode == kModeL2) launch_accumulate<kModeL2>(tt, C, grid, st, a, sa);
   else if (mode == kModeRobust) launch_accumulate<kModeRobust>(tt, C, grid, st, a, sa);
+  else if (mode == kModeL2First && g_accum_variant == 2) launch_accumulate<kModeL2First>(tt, C, grid, st, a, sa);
+  else if (mode == kModeL2First) launch_accumulate<kModeRobust>(tt, C, grid, st, a, sa);  // v1: weights 1 at run time
   else launch_accumulate<kModeHessian>(tt, C, grid, st, a, sa);
 }
 
@@ -609,7 +611,7 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
       la.robust_type = first_l2 ? (int)ICA_QUADRATIC : pr->robust_type;
       const bool fuse = nb <= g_fuse_solve && g_accum_variant == 2;
       sa.tickets = fuse ? ctx->tickets.as<int>() : nullptr;
-      launch_accumulate_mode((robust || first_l2) ? kModeRobust : kModeL2, tt, C, dim3(lg.tiles, nb), st, la, sa);
+      launch_accumulate_mode(robust ? kModeRobust : first_l2 ? kModeL2First : kModeL2, tt, C, dim3(lg.tiles, nb), st, la, sa);
       if (ctx->profiling) {
         ICA_TRY(next_event(&e1));
         ICA_HIP(ctx, hipEventRecord(ctx->ev_pool[e1], st));

@@ -18,7 +18,7 @@ constexpr int kTileW = 64;    // one lane per column of a tile
 constexpr int kWaves = kBlock / 64;
 constexpr int kFlush = 8;     // fp32 partial sums are promoted to fp64 every kFlush pixels per thread
 
-enum Mode { kModeL2 = 0, kModeRobust = 1, kModeHessian = 2 };
+enum Mode { kModeL2 = 0, kModeRobust = 1, kModeHessian = 2, kModeL2First = 3 };
 
 #ifndef ICA_FLAT_BELOW
 #define ICA_FLAT_BELOW 8
@@ -170,6 +170,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 //   MODE kModeL2      b = sum DIJ^T DI                      over F & V(p)
 //   MODE kModeRobust  b and H = sum rho' DIJ^T DIJ           (rho'(0) where the warp is outside)
 //   MODE kModeHessian H = sum DIJ^T DIJ over F               (L2 setup, no warp)
+//   MODE kModeL2First b and H with weights 1                 (first L2 iteration of a level; accumulate2 only)
 // F = pixels outside the NaN frame, V(p) = pixels whose 4x4 footprint is inside I2.
 // One workgroup = one 64 x tile_h tile of one pair; lane = column, the 4 waves interleave rows.
 template <int TT, int MODE, int C>
