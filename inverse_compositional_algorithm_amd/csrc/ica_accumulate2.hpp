@@ -109,7 +109,7 @@ __device__ __forceinline__ void displacement_col(const float* A, float cx, float
   float ny = fmaf(A[4], yf, cy);
   if constexpr (PROJ) {
     const float g = fmaf(A[7], yf, gx);
-    const float r = 1.0f / (1.0f + g);
+    const float r = rcp_nr(1.0f + g);
     nx = (nx - xf * g) * r;
     ny = (ny - yf * g) * r;
   }

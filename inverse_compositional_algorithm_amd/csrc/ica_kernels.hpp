@@ -114,7 +114,7 @@ __device__ __forceinline__ void displacement(const float* a, float x, float y, f
   float ny = fmaf(a[3], x, fmaf(a[4], y, a[5]));
   if constexpr (PROJ) {
     const float g = fmaf(a[6], x, a[7] * y);
-    const float r = 1.0f / (1.0f + g);
+    const float r = rcp_nr(1.0f + g);
     nx = (nx - x * g) * r;
     ny = (ny - y * g) * r;
   }

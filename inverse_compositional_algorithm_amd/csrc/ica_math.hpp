@@ -226,6 +226,18 @@ __host__ __device__ inline bool lu_inverse(int n, const double* H, double* Hinv,
   return true;
 }
 
+// 1/d and 1/sqrt(d) in fp32: hardware estimate (1 ulp) + one Newton step, ~4 instructions instead of the ~10 of the
+// IEEE division sequence -- these sit in the per-pixel loop of the projective and the robust kernels.
+__device__ __forceinline__ float rcp_nr(float d) {
+  const float r = __builtin_amdgcn_rcpf(d);
+  return __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+}
+__device__ __forceinline__ float rsqrt_nr(float d) {
+  const float r = __builtin_amdgcn_rsqf(d);
+  const float h = 0.5f * d * r;
+  return __builtin_fmaf(__builtin_fmaf(-h, r, 0.5f), r, r);
+}
+
 // rho'(t^2; lambda) (image_optimisation.py:17-53).  TRUNCATED_QUADRATIC raises in the reference when
 // given an array (:40); the element-wise reading is implemented (documented extension).
 __device__ inline float rho_prime(float t2, float lam2, int type) {
@@ -233,10 +245,10 @@ __device__ inline float rho_prime(float t2, float lam2, int type) {
     case ICA_TRUNCATED_QUADRATIC: return t2 < lam2 ? 1.0f : 0.0f;
     case ICA_GERMAN_MCCLURE: {
       const float s = lam2 + t2;
-      return lam2 / (s * s);
+      return lam2 * rcp_nr(s * s);
     }
-    case ICA_LORENTZIAN: return 1.0f / (lam2 + t2);
-    case ICA_CHARBONNIER: return 1.0f / sqrtf(t2 + lam2);
+    case ICA_LORENTZIAN: return rcp_nr(lam2 + t2);
+    case ICA_CHARBONNIER: return rsqrt_nr(t2 + lam2);
     default: return 1.0f;
   }
 }
