@@ -18,7 +18,7 @@
 //      sum_y y^b G* and sum_y y^b S** are accumulated (4 FMAs for affine L2 instead of 6 products + 6 FMAs;
 //      12 + 5 instead of (36 + 8 + 8) * C for robust homography, independent of C).  The x powers are applied
 //      once per tile, in fp64, when the 64 lanes' moments are folded into the <= 44 sums.
-//   fp32 per pixel, promoted to fp64 after every wave band; fixed summation order throughout (deterministic).
+//   fp32 per pixel, promoted to fp64 at the end of the tile; fixed summation order throughout (deterministic).
 #pragma once
 #include <type_traits>
 
