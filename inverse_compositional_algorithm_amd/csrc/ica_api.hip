@@ -3,6 +3,7 @@
 // ica_kernels.hpp on the context's stream; there is no CPU compute path.
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -244,7 +245,9 @@ int launch_pyramid_down(ica_ctx* ctx, int batch, int C, int H, int W, int h, int
   }
   ICA_HIP(ctx, ctx->tmp_resample.ensure((size_t)planes * h * W * sizeof(float)));
   float* tmp = ctx->tmp_resample.as<float>();
-  const int vgroups = (h + kOutsV - 1) / kOutsV, xblocks = (W + 63) / 64;
+  // 16-byte loads per lane in the vertical pass when rows and base pointers are 16-byte aligned, else 4-byte ones
+  const bool vec4 = W % 4 == 0 && ((uintptr_t)in % 16) == 0;
+  const int vgroups = (h + kOutsV - 1) / kOutsV, xblocks = vec4 ? (W + 255) / 256 : (W + 63) / 64;
   const int per_pair = C * vgroups * xblocks;  // min/max partials per pair written by the vertical pass
   float* part = nullptr;
   if (oy->vcover) {
@@ -257,18 +260,27 @@ int launch_pyramid_down(ica_ctx* ctx, int batch, int C, int H, int W, int h, int
   const int step = std::max(C, (32768 / C) * C);
   for (int p0 = 0; p0 < planes; p0 += step) {
     const int np = std::min(step, planes - p0);
-    hipLaunchKernelGGL(ica_resample_v_kernel, dim3(xblocks, (vgroups + kWaves - 1) / kWaves, np), dim3(kBlock), 0, ctx->stream,
-                       in + (size_t)p0 * H * W, tmp + (size_t)p0 * h * W, np, C, W, oy->view(),
-                       part ? part + (size_t)p0 * vgroups * xblocks * 2 : nullptr);
+    const dim3 gv(xblocks, (vgroups + kWaves - 1) / kWaves, np);
+    float* pp = part ? part + (size_t)p0 * vgroups * xblocks * 2 : nullptr;
+    if (vec4)
+      hipLaunchKernelGGL(ica_resample_v_kernel<4>, gv, dim3(kBlock), 0, ctx->stream, in + (size_t)p0 * H * W,
+                         tmp + (size_t)p0 * h * W, np, C, W, oy->view(), pp);
+    else
+      hipLaunchKernelGGL(ica_resample_v_kernel<1>, gv, dim3(kBlock), 0, ctx->stream, in + (size_t)p0 * H * W,
+                         tmp + (size_t)p0 * h * W, np, C, W, oy->view(), pp);
   }
   if (part)
     hipLaunchKernelGGL(ica_minmax_final_kernel, dim3((batch + kWaves - 1) / kWaves), dim3(kBlock), 0, ctx->stream, part, per_pair, batch,
                        mm_out);
   for (int p0 = 0; p0 < planes; p0 += step) {
     const int np = std::min(step, planes - p0);
-    hipLaunchKernelGGL(ica_resample_h_kernel, dim3((w + 63) / 64, (h + kRowsH - 1) / kRowsH, np), dim3(kBlock), lds,
-                       ctx->stream, tmp + (size_t)p0 * h * W, out + (size_t)p0 * h * w, np, C, h, ox->view(),
-                       mm_out + (size_t)(p0 / C) * 2, ox->span_pad);
+    const dim3 gh((w + 63) / 64, (h + kRowsH - 1) / kRowsH, np);
+    if (W % 2 == 0)  // rows of the intermediate image are 8-byte aligned: stage with 8-byte loads
+      hipLaunchKernelGGL(ica_resample_h_kernel<true>, gh, dim3(kBlock), lds, ctx->stream, tmp + (size_t)p0 * h * W,
+                         out + (size_t)p0 * h * w, np, C, h, ox->view(), mm_out + (size_t)(p0 / C) * 2, ox->span_pad);
+    else
+      hipLaunchKernelGGL(ica_resample_h_kernel<false>, gh, dim3(kBlock), lds, ctx->stream, tmp + (size_t)p0 * h * W,
+                         out + (size_t)p0 * h * w, np, C, h, ox->view(), mm_out + (size_t)(p0 / C) * 2, ox->span_pad);
   }
   ICA_HIP(ctx, hipGetLastError());
   return ICA_OK;

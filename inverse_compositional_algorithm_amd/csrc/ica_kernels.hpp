@@ -765,16 +765,20 @@ constexpr int kVWin = 160;   // max input samples spanned by 16 consecutive outp
 constexpr int kRowsH = 32;   // rows per workgroup in the horizontal pass (8 per wave)
 
 // Vertical pass: in [planes][n_in][W] -> out [planes][n_out][W]  (+ optional min/max of `in` per pair).
-// lane = column (coalesced 256-B row segments); each wave produces kOutsV consecutive output rows, so every input
-// value is loaded once and feeds kOutsV FMAs whose weights are wave-uniform: they come through the scalar cache into
-// SGPRs (s_load_dwordx8/x16 per input row), the vector ALU only sees v_fmac / v_pk_fma(acc, sgpr, value).
+// A lane owns VEC adjacent columns (VEC = 4: one 16-byte load per input row and lane, 1 KiB per wave -- with 4-byte
+// loads the pass sits at the rate the texture addresser takes dword loads, not at a memory rate); each wave produces
+// kOutsV consecutive output rows, so every input value is loaded once and feeds kOutsV FMAs whose weights are
+// wave-uniform: they come through the scalar cache into SGPRs (s_load_dwordx8/x16 per input row), the vector ALU
+// only sees v_fmac / v_pk_fma(acc, sgpr, value).
 // The operator weights are float64 on the host (ica_pyramid.hpp); they are applied in fp32 like every other
 // per-pixel quantity of the engine (the result is stored as fp32 anyway).
+template <int VEC>
 __global__ __launch_bounds__(kBlock) void ica_resample_v_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                                 int planes, int channels, int W, BandOp op,
                                                                 float* __restrict__ mm_part) {
+  typedef float vecf __attribute__((ext_vector_type(VEC)));
   const int lane = threadIdx.x & 63;
-  const int x = blockIdx.x * 64 + lane;
+  const int x = (blockIdx.x * 64 + lane) * VEC;  // (VEC > 1 only when W % VEC == 0: a lane is in or out as a whole)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = blockIdx.y * kWaves + wave;
   const int o0 = g * kOutsV;
@@ -784,9 +788,11 @@ __global__ __launch_bounds__(kBlock) void ica_resample_v_kernel(const float* __r
   const int j0 = op.vj0[g], span = op.vspan[g];
   const int own0 = mm_part ? op.vown0[g] - j0 : 0, own1 = mm_part ? op.vown1[g] - j0 : 0;
   const float* __restrict__ wz = op.vw + (size_t)g * kVWin * kOutsV;
-  float acc[kOutsV];
+  float acc[kOutsV][VEC];
 #pragma unroll
-  for (int i = 0; i < kOutsV; ++i) acc[i] = 0.f;
+  for (int i = 0; i < kOutsV; ++i)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[i][v] = 0.f;
   const bool xin = x < W;
   const float* col = in + (size_t)pl * op.n_in * W + (size_t)j0 * W + (xin ? x : 0);
   float lo = INFINITY, hi = -INFINITY;
@@ -794,10 +800,24 @@ __global__ __launch_bounds__(kBlock) void ica_resample_v_kernel(const float* __r
     constexpr bool TRACK = decltype(track_c)::value;
 #pragma unroll 4
     for (int jj = a; jj < b; ++jj) {
-      const float v = col[(size_t)jj * W];
-      if constexpr (TRACK) { lo = fminf(lo, v); hi = fmaxf(hi, v); }
+      float val[VEC];
+      if constexpr (VEC == 1) {
+        val[0] = col[(size_t)jj * W];
+      } else {
+        const vecf t = *reinterpret_cast<const vecf*>(col + (size_t)jj * W);
 #pragma unroll
-      for (int i = 0; i < kOutsV; ++i) acc[i] = fmaf(wz[jj * kOutsV + i], v, acc[i]);
+        for (int v = 0; v < VEC; ++v) val[v] = t[v];
+      }
+      if constexpr (TRACK) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) { lo = fminf(lo, val[v]); hi = fmaxf(hi, val[v]); }
+      }
+#pragma unroll
+      for (int i = 0; i < kOutsV; ++i) {
+        const float w = wz[jj * kOutsV + i];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[i][v] = fmaf(w, val[v], acc[i][v]);
+      }
     }
   };
   run(0, own0, std::false_type{});
@@ -805,8 +825,19 @@ __global__ __launch_bounds__(kBlock) void ica_resample_v_kernel(const float* __r
   run(own1, span, std::false_type{});
   if (xin) {
 #pragma unroll
-    for (int i = 0; i < kOutsV; ++i)
-      if (i < no) out[((size_t)pl * op.n_out + o0 + i) * W + x] = acc[i];
+    for (int i = 0; i < kOutsV; ++i) {
+      if (i < no) {
+        float* dst = out + ((size_t)pl * op.n_out + o0 + i) * W + x;
+        if constexpr (VEC == 1) {
+          dst[0] = acc[i][0];
+        } else {
+          vecf t;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) t[v] = acc[i][v];
+          *reinterpret_cast<vecf*>(dst) = t;
+        }
+      }
+    }
   }
   if (mm_part) {  // one partial per wave, reduced by ica_minmax_final_kernel (no atomics: 256 waves share a pair)
 #pragma unroll
@@ -829,6 +860,7 @@ __global__ __launch_bounds__(kBlock) void ica_resample_v_kernel(const float* __r
 // stored de-interleaved (even input columns, then odd ones): with a decimation factor of 2 consecutive lanes
 // read input columns 2 apart, which this layout turns into consecutive LDS words (no 2-way bank conflict); any
 // other factor is still correct, only less regular.
+template <bool PAIRS>
 __global__ __launch_bounds__(kBlock) void ica_resample_h_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                                 int planes, int channels, int H, BandOp op,
                                                                 const float* __restrict__ minmax, int span_pad) {
@@ -839,7 +871,37 @@ __global__ __launch_bounds__(kBlock) void ica_resample_h_kernel(const float* __r
   const int span = op.start[o_last] + op.K - c0;  // <= span_pad
   const int half = (span_pad + 1) >> 1;
   const float* src = in + (size_t)pl * H * op.n_in;
-  {
+  if constexpr (PAIRS) {
+    // staging with 8-byte loads: a lane reads the input columns (2j, 2j+1) of the global image -- whose relative
+    // position c = x - c0 decides the half of the de-interleaved row they go to -- 8 rows x 2 segments of 128 columns
+    // per wave in flight together (n_in is even and the rows 8-byte aligned, host-checked)
+    const int lane_c = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x0 = c0 & ~1;  // first global column pair
+    constexpr int kSeg = 2;
+    for (int cs = 0; cs < span + 1; cs += 128 * kSeg) {
+      float2 v[kRowsH / kWaves][kSeg];
+#pragma unroll
+      for (int i = 0; i < kRowsH / kWaves; ++i) {
+        const int y = r_base + wv + i * kWaves;
+#pragma unroll
+        for (int j = 0; j < kSeg; ++j) {
+          const int xg = x0 + cs + j * 128 + 2 * lane_c;  // even; xg + 1 < n_in whenever xg < n_in
+          v[i][j] = (xg - c0 < span && y < H && xg < op.n_in)
+                        ? *reinterpret_cast<const float2*>(src + (size_t)y * op.n_in + xg) : make_float2(0.f, 0.f);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < kRowsH / kWaves; ++i) {
+        const int r = wv + i * kWaves;
+#pragma unroll
+        for (int j = 0; j < kSeg; ++j) {
+          const int c = x0 + cs + j * 128 + 2 * lane_c - c0;  // -1 or even first lane when c0 is odd
+          if (c >= 0 && c < span) tile[r * span_pad + (c & 1) * half + (c >> 1)] = v[i][j].x;
+          if (c + 1 >= 0 && c + 1 < span) tile[r * span_pad + ((c + 1) & 1) * half + ((c + 1) >> 1)] = v[i][j].y;
+        }
+      }
+    }
+  } else {
     // staging: 8 rows x up to 4 column segments per wave are read into registers first (all loads in flight
     // together), then written to LDS
     const int lane_c = threadIdx.x & 63, wv = threadIdx.x >> 6;
