@@ -468,6 +468,15 @@ __device__ __forceinline__ void solve_pair(const SolveArgs& a, int slot, int pai
   // the stored inverse (L2, iterations >= 1) is fetched while the partials are being gathered
   double hpre = 0.0;
   if (!a.invert_h && threadIdx.x < kMaxN * kMaxN) hpre = a.Hinv[(size_t)pair * 64 + threadIdx.x];
+  // ... and so is the per-pair state thread 0 needs at the end (one memory round trip instead of three in its tail)
+  double pcur[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lam = 0.0;
+  int it = 0;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pcur[i] = a.p[(size_t)pair * 8 + i];
+    lam = a.lambda_it[pair];
+    it = a.niter[pair];
+  }
   gather_partials(a.partials, slot, a.tiles, s, scratch + kAccStride, 0, a.invert_h ? kAccStride : kMaxN);
   const int n = a.n;
   const double* hinv = Hi;
@@ -513,19 +522,20 @@ __device__ __forceinline__ void solve_pair(const SolveArgs& a, int slot, int pai
   const double err = sqrt(e2);
   double* p = a.p + (size_t)pair * 8;
   double* pp = a.p_prev + (size_t)pair * 8;
-  for (int i = 0; i < 8; ++i) pp[i] = p[i];
-  update_transform(p, dp, a.tt, (a.flags & ICA_FLAG_EXACT_UPDATE) != 0);  // transformation.py:35-141
-  double lam = a.lambda_it[pair];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) pp[i] = pcur[i];
+  update_transform(pcur, dp, a.tt, (a.flags & ICA_FLAG_EXACT_UPDATE) != 0);  // transformation.py:35-141
+#pragma unroll
+  for (int i = 0; i < 8; ++i) p[i] = pcur[i];
   if (a.robust && a.lambda_user <= 0.0 && lam > a.lambdaN) {  // ref :235-238 (decay after use)
     lam *= a.lambda_ratio;
     if (lam < a.lambdaN) lam = a.lambdaN;
     a.lambda_it[pair] = lam;
   }
-  const int it = a.niter[pair];
   if (a.trace) {
     double* tr = a.trace + (((size_t)pair * a.nscales + a.level) * a.max_iter + it) * ICA_TRACE_STRIDE;
     tr[0] = err;
-    for (int i = 0; i < 8; ++i) tr[1 + i] = (i < n) ? p[i] : 0.0;
+    for (int i = 0; i < 8; ++i) tr[1 + i] = (i < n) ? pcur[i] : 0.0;
     tr[9] = lam;
   }
   a.error[pair] = err;
