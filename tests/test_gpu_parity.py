@@ -250,26 +250,38 @@ def test_deterministic(eng):
     assert torch.equal(a.p, b.p) and torch.equal(a.niter, b.niter)
 
 
-def test_fused_solve_option_gives_the_same_iterates(eng, monkeypatch):
-    """ICA_FUSE_SOLVE (last-arriving tile runs the solve inside the iteration kernel) is an alternative schedule of the
-    same arithmetic: identical iteration counts and parameters equal to rounding."""
+def test_alternative_schedules_give_the_same_iterates(eng):
+    """The library's optional code paths are alternative schedules of the same arithmetic: the last-arriving tile
+    running the solve inside the iteration kernel (ICA_FUSE_SOLVE), a separate Hessian pass per level instead of the
+    folded first iteration (ICA_SEPARATE_HESSIAN), the direct-gather iteration kernel (ICA_ACCUM=1), 16-row tiles
+    everywhere (ICA_MAX_TILE_H).  Identical iteration counts, parameters equal to rounding -- on an L2 and on a robust
+    problem (the options are read when a context is created, hence one process per setting)."""
     import os
     import subprocess
     import sys
     code = ("import numpy as np, torch, sys; sys.path.insert(0, %r);"
             "from inverse_compositional_algorithm_amd.engine import IcaEngine;"
-            "e = IcaEngine(0); I1, I2, _ = e.make_batch(5, 16, 128, 160, 1, 5, robust_clutter=True);"
-            "r = e.solve(I1, I2, e.problem(16, 128, 160, 1, 5, 3, nscales=2, delta=5));"
-            "np.save(sys.argv[1], np.concatenate([r.p.cpu().numpy().ravel(), r.niter.cpu().numpy().ravel()]))"
+            "e = IcaEngine(0); out = [];\n"
+            "for t, r in ((5, 3), (4, 0)):\n"
+            "    I1, I2, _ = e.make_batch(5, 16, 128, 160, 1, t, robust_clutter=(r != 0))\n"
+            "    q = e.solve(I1, I2, e.problem(16, 128, 160, 1, t, r, nscales=2, delta=5))\n"
+            "    out += [q.p.cpu().numpy().ravel(), q.niter.cpu().numpy().ravel().astype(float)]\n"
+            "np.save(sys.argv[1], np.concatenate(out))"
             % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    outs = []
-    for fuse in ("0", "1000"):
-        path = f"/tmp/ica_fuse_{fuse}.npy"
-        env = dict(os.environ, ICA_FUSE_SOLVE=fuse)
-        subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=300)
-        outs.append(np.load(path))
-    np.testing.assert_array_equal(outs[0][-32:], outs[1][-32:])          # iteration counts
-    np.testing.assert_allclose(outs[0][:-32], outs[1][:-32], rtol=1e-9, atol=1e-12)
+    outs = {}
+    for name, extra in (("default", {}), ("fused_solve", {"ICA_FUSE_SOLVE": "1000"}),
+                        ("separate_hessian", {"ICA_SEPARATE_HESSIAN": "1"}), ("direct_gather", {"ICA_ACCUM": "1"}),
+                        ("short_tiles", {"ICA_MAX_TILE_H": "16"})):
+        path = f"/tmp/ica_schedule_{name}.npy"
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, **extra), timeout=300)
+        outs[name] = np.load(path)
+    ref = outs.pop("default").reshape(2, -1)  # per problem: 16 x 8 parameters, then 16 x 2 iteration counts
+    for name, o in outs.items():
+        o = o.reshape(2, -1)
+        np.testing.assert_array_equal(o[:, 128:], ref[:, 128:], err_msg=name)                  # iteration counts
+        # (the direct-gather kernel forms its per-pixel products in another order: fp32 rounding differs)
+        tol = 1e-4 if name == "direct_gather" else 1e-6
+        np.testing.assert_allclose(o[:, :128], ref[:, :128], rtol=tol, atol=tol * 1e-2, err_msg=name)
 
 
 EDGE = [
