@@ -117,8 +117,13 @@ inline HostBandOp build_rescale_op(int n_in, int n_out) {
     if (hi < lo) { lo = 0; hi = 0; }
     op.start[o] = lo;
     last[o] = hi;
-    K = std::max(K, hi - lo + 1);
   }
+  // The device passes take the first output of a group / tile as the one with the smallest start and the last as the
+  // one with the largest end, i.e. they need non-decreasing starts.  Thresholding each row on its own does not give
+  // that for non-integer factors (a start can step back by one): start every band at the smallest start of the
+  // outputs that follow it, and size the common band length for that.
+  for (int o = n_out - 2; o >= 0; --o) op.start[o] = std::min(op.start[o], op.start[o + 1]);
+  for (int o = 0; o < n_out; ++o) K = std::max(K, last[o] - op.start[o] + 1);
   op.K = K;
   op.w.assign((size_t)n_out * K, 0.0);
   for (int o = 0; o < n_out; ++o)

@@ -178,6 +178,19 @@ def test_pyramid_down(eng, shape, C):
         np.testing.assert_allclose(got[i], want, atol=1e-4)
 
 
+@pytest.mark.parametrize("nu", [0.75, 0.6, 0.4, 0.3, 0.25])
+def test_pyramid_down_other_factors(eng, nu):
+    """`nu` is a caller's choice (config.ini): non-dyadic and stronger decimations use wider operators (more taps,
+    longer input windows per group of outputs) through the same two passes."""
+    rng = np.random.default_rng(int(nu * 100))
+    imgs = [np.round(rng.uniform(0, 255, (150, 202, 1))) for _ in range(2)]
+    got = to_np(eng.pyramid_down(to_dev(eng, *imgs), nu))
+    for i in range(2):
+        want = oc.rescale_restated(imgs[i], nu)
+        assert got[i].shape == want.shape
+        np.testing.assert_allclose(got[i], want, atol=2e-4)
+
+
 def test_zoom_in_parameters(eng):
     for t in TYPES:
         p = np.zeros((3, 8))
