@@ -332,3 +332,52 @@ def test_edge_cases_match_oracle(eng, case):
     Iw = to_np(res.Iw)[0]
     assert np.array_equal(np.isnan(Iw), np.isnan(Iw_w)), name
     np.testing.assert_allclose(np.nan_to_num(Iw), np.nan_to_num(Iw_w), atol=2e-2)
+
+
+@pytest.mark.parametrize("t", [oc.AFFINITY, oc.HOMOGRAPHY])
+def test_exact_update_flag_matches_oracle_exact_composition(eng, t):
+    """ICA_FLAG_EXACT_UPDATE: the exact composition p o dp^-1 instead of the reference's two deviating closed forms
+    (transformation.py:106, :136); the oracle implements both."""
+    from inverse_compositional_algorithm_amd._lib import ICA_FLAG_EXACT_UPDATE
+    n = oc.nparams(t)
+    I1, I2, _ = syn.make_pair(611 + t, 112, 144, 3, t)
+    prob = eng.problem(1, 112, 144, 3, t, 0, nscales=2, delta=5, flags=ICA_FLAG_EXACT_UPDATE)
+    res = eng.solve(to_dev(eng, I1), to_dev(eng, I2), prob)
+    want, _, _, _, nit = oc.ica_pyramidal(I1.astype(np.float64), I2.astype(np.float64), np.zeros(n), t, 2, 0.5, 1e-3, 0, 0.0,
+                                         True, 5, exact_update=True)
+    ref_form, _, _, _, _ = oc.ica_pyramidal(I1.astype(np.float64), I2.astype(np.float64), np.zeros(n), t, 2, 0.5, 1e-3, 0,
+                                            0.0, True, 5, exact_update=False)
+    p = res.p[0, :n].cpu().numpy()
+    assert list(res.niter[0].cpu().numpy()) == nit
+    assert np.linalg.norm(p - want) / np.linalg.norm(want) <= 1e-4
+    assert np.linalg.norm(p - want) < 0.1 * np.linalg.norm(want - ref_form) or np.allclose(want, ref_form, rtol=1e-7)
+
+
+@pytest.mark.parametrize("nu,ns", [(0.6, 3), (0.75, 3), (0.4, 2)])
+def test_full_solve_with_other_pyramid_factors(eng, nu, ns):
+    """nu != 0.5: level sizes by round-half-even (zoom.py:20-21), non-dyadic rescale operators, zoom_in_parameters with
+    nu' = max of the two size ratios (zoom.py:62-125)."""
+    t, n = oc.SIMILARITY, 4
+    I1, I2, _ = syn.make_pair(777, 150, 202, 3, t)
+    prob = eng.problem(1, 150, 202, 3, t, oc.CHARBONNIER, nscales=ns, nu=nu, delta=4)
+    res = eng.solve(to_dev(eng, I1), to_dev(eng, I2), prob)
+    want, _, _, _, nit = oc.ica_pyramidal(I1.astype(np.float64), I2.astype(np.float64), np.zeros(n), t, ns, nu, 1e-3,
+                                         oc.CHARBONNIER, 0.0, True, 4)
+    assert list(res.niter[0].cpu().numpy()) == nit
+    p = res.p[0, :n].cpu().numpy()
+    assert np.linalg.norm(p - want) / np.linalg.norm(want) <= 1e-4
+
+
+def test_odd_batch_and_short_iteration_cap(eng):
+    """13 pairs (not a multiple of the 8 list shards / XCDs) and max_iter = 4: every pair stops at the cap or at TOL,
+    exactly like max_iter single-scale oracle runs."""
+    t, n, B = oc.AFFINITY, 6, 13
+    pairs = [syn.make_pair(900 + i, 96, 128, 1, t) for i in range(B)]
+    I1s, I2s = [a for a, _, _ in pairs], [b for _, b, _ in pairs]
+    prob = eng.problem(B, 96, 128, 1, t, 0, nscales=1, delta=5, max_iter=4)
+    res = eng.solve(to_dev(eng, *I1s), to_dev(eng, *I2s), prob)
+    for i in range(B):
+        want, _, _, _, nit = oc.ica_single_scale(I1s[i].astype(np.float64), I2s[i].astype(np.float64), np.zeros(n), t, 1e-3, 0,
+                                                0.0, True, 5, max_iter=4)
+        assert int(res.niter[i, 0]) == nit
+        assert np.linalg.norm(res.p[i, :n].cpu().numpy() - want) / np.linalg.norm(want) <= 1e-4
