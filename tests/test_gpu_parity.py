@@ -383,11 +383,11 @@ def test_odd_batch_and_short_iteration_cap(eng):
         assert np.linalg.norm(res.p[i, :n].cpu().numpy() - want) / np.linalg.norm(want) <= 1e-4
 
 
-def _fuzz_cases(count, seed):
+def _fuzz_cases(count, seed, hmax=150, wmax=210):
     rng = np.random.default_rng(seed)
     out = []
     for k in range(count):
-        H_, W_ = int(rng.integers(40, 150)), int(rng.integers(40, 210))
+        H_, W_ = int(rng.integers(40, hmax)), int(rng.integers(40, wmax))
         C = int(rng.choice([1, 3]))
         t = int(rng.integers(1, 6))
         r = int(rng.choice([0, 0, 2, 3, 4]))

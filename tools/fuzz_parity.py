@@ -7,8 +7,9 @@ import test_gpu_parity as tp
 from inverse_compositional_algorithm_amd.engine import IcaEngine
 eng = IcaEngine(0)
 n, seed = int(sys.argv[1]), int(sys.argv[2])
+hmax, wmax = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (150, 210)
 bad = capped = 0
-for case in tp._fuzz_cases(n, seed):
+for case in tp._fuzz_cases(n, seed, hmax, wmax):
     try:
         tp.test_seeded_random_configurations_match_oracle(eng, case)
     except AssertionError as e:
