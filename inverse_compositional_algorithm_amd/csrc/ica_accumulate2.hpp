@@ -118,7 +118,7 @@ __device__ __forceinline__ void displacement_col(const float* A, float cx, float
 }
 
 template <int TT, int MODE, int C>
-__global__ __launch_bounds__(kBlock) void ica_accumulate2_kernel(LevelArgs a, SolveArgs sa) {
+__global__ __launch_bounds__(kBlock) void ica_accumulate2_kernel(LevelArgs a) {
   constexpr int N = NP<TT>::n;
   constexpr int NT = N * (N + 1) / 2;
   constexpr bool kB = (MODE != kModeHessian);
@@ -192,7 +192,9 @@ __global__ __launch_bounds__(kBlock) void ica_accumulate2_kernel(LevelArgs a, So
   const bool col_ok = (x < W) & !(frame_on & ((x < a.delta) | (x >= W - a.delta)));
   const float cmx = ((x >= 1) & (x <= W - 2)) ? 1.0f : 0.0f;  // ref :81: the 1-px border keeps a zero x-derivative
   const float cx = fmaf(A[0], xf, A[2]), cy = fmaf(A[3], xf, A[5]), gxc = A[6] * xf;
-  const float vx_lo = (float)(1 - x), vx_hi = (float)(W - 3 - x), vy_hi = (float)(H - 3);
+  const int xm1 = x - 1;
+  const unsigned ux_max = (unsigned)(W - 4), uy_max = (unsigned)(H - 4);
+  const bool can_sample = (W >= 4) & (H >= 4);  // else the unsigned range tests below would wrap
   const bool w4 = (W & 3) == 0;                         // rows are 16-byte aligned -> 16-B LDS-DMA
 
   // ---- plan: lane c computes the I2 footprint of chunk c (bit 30 = stage through LDS, bit 29 = skip) ----
@@ -414,17 +416,19 @@ __global__ __launch_bounds__(kBlock) void ica_accumulate2_kernel(LevelArgs a, So
         float dxw, dyw;
         displacement_col<kProj>(A, cx, cy, gxc, xf, yf, dxw, dyw);
         const float flx = floorf(dxw), fly = floorf(dyw);
-        // 4x4 footprint inside the image (bicubic_interpolation.py:199, cval=nan); float compares, so a NaN or
-        // infinite position is simply "outside"
-        const float y0f = yf + fly;  // exact: both are integers far below 2^24
-        const bool valid = live & (flx >= vx_lo) & (flx <= vx_hi) & (y0f >= 1.0f) & (y0f <= vy_hi);
-        const int x0 = x + (int)flx, y0 = y + (int)fly;
+        // 4x4 footprint inside the image (bicubic_interpolation.py:199, cval=nan), tested on the integer position of
+        // tap (0,0): ux = x0 - 1 in [0, W-4], uy = y0 - 1 in [0, H-4], one unsigned compare each.  An infinite position
+        // saturates in the conversion and lands outside; a NaN position converts to 0, may pass, and is caught by the
+        // finiteness test on the residual below (NaN weights -> NaN sample -> residual 0), which is what "outside"
+        // amounts to as well.
+        const int ux = (int)flx + xm1, uy = (int)fly + (y - 1);
+        const bool valid = live & can_sample & ((unsigned)ux <= ux_max) & ((unsigned)uy <= uy_max);
         float wx[4], wy[4];
         keys_weights(dxw - flx, wx);
         keys_weights(dyw - fly, wy);
         float iw[C];
         if constexpr (STAGED) {
-          const int aoff_raw = __mul24(y0 - 1 - y_lo, P2) + (x0 - 1 - x_lo);
+          const int aoff_raw = __mul24(uy, P2) + ux - (y_lo * P2 + x_lo);
           const int aoff = valid ? aoff_raw : 0;
           const float* t = b2 + aoff;
 #pragma unroll
@@ -442,7 +446,7 @@ __global__ __launch_bounds__(kBlock) void ica_accumulate2_kernel(LevelArgs a, So
             iw[c] = v;
           }
         } else {
-          const float* t = I2 + (valid ? (size_t)(y0 - 1) * W + (x0 - 1) : 0);
+          const float* t = I2 + (valid ? (size_t)uy * W + ux : 0);
 #pragma unroll
           for (int c = 0; c < C; ++c) {
             const float* q = t + c * plane;
@@ -474,11 +478,21 @@ __global__ __launch_bounds__(kBlock) void ica_accumulate2_kernel(LevelArgs a, So
         for (int c = 0; c < C; ++c) t2 = fmaf(di[c], di[c], t2);
         w = live ? rho_prime(t2, lam2, a.robust_type) : 0.0f;  // rho'(0) where the warp is outside
       }
+      // one channel and a weighted sum: fold the weight into the gradient once (w Ix, w Iy) instead of scaling
+      // gx, gy, sxx, sxy, syy one by one
+      constexpr bool kFoldW = (C == 1) && kH;
+      float wix = 0.f, wiy = 0.f;
+      if constexpr (kFoldW) { wix = w * ix2[0]; wiy = w * iy2[0]; }
       if constexpr (kB) {
         float gx = 0.f, gy = 0.f;
+        if constexpr (kFoldW) {
+          gx = wix * di[0];
+          gy = wiy * di[0];
+        } else {
 #pragma unroll
-        for (int c = 0; c < C; ++c) { gx = fmaf(ix2[c], di[c], gx); gy = fmaf(iy2[c], di[c], gy); }
-        if constexpr (MODE == kModeRobust) { gx *= w; gy *= w; }
+          for (int c = 0; c < C; ++c) { gx = fmaf(ix2[c], di[c], gx); gy = fmaf(iy2[c], di[c], gy); }
+          if constexpr (MODE == kModeRobust) { gx *= w; gy *= w; }
+        }
         m32[ML::ogx] += gx;
         if constexpr (ML::mbx >= 1) m32[ML::ogx + 1] = fmaf(gx, yf, m32[ML::ogx + 1]);
         m32[ML::ogy] += gy;
@@ -487,13 +501,19 @@ __global__ __launch_bounds__(kBlock) void ica_accumulate2_kernel(LevelArgs a, So
       }
       if constexpr (kH) {
         float sxx = 0.f, sxy = 0.f, syy = 0.f;
+        if constexpr (kFoldW) {
+          sxx = wix * ix2[0];
+          sxy = wix * iy2[0];
+          syy = wiy * iy2[0];
+        } else {
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-          sxx = fmaf(ix2[c], ix2[c], sxx);
-          sxy = fmaf(ix2[c], iy2[c], sxy);
-          syy = fmaf(iy2[c], iy2[c], syy);
+          for (int c = 0; c < C; ++c) {
+            sxx = fmaf(ix2[c], ix2[c], sxx);
+            sxy = fmaf(ix2[c], iy2[c], sxy);
+            syy = fmaf(iy2[c], iy2[c], syy);
+          }
+          sxx *= w; sxy *= w; syy *= w;
         }
-        sxx *= w; sxy *= w; syy *= w;
         float yp = 1.0f;
 #pragma unroll
         for (int b = 0; b < 5; ++b) {
@@ -587,41 +607,7 @@ __global__ __launch_bounds__(kBlock) void ica_accumulate2_kernel(LevelArgs a, So
     if (q == 0 && have) {
       double* out = a.partials + ((size_t)pair_slot * ntiles + tile_id) * kAccStride;  // indexed by launch slot
       double* dst = out + (e < N ? e : kMaxN + (e - N));
-      if (kB && sa.tickets)  // fused solve: write-through (sc1) store, so no L2 write-back fence is needed below
-        __hip_atomic_store(dst, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else
-        *dst = val;
-    }
-  }
-
-  // ---- fused solve: the last tile of a pair to arrive sums the pair's partials, solves and updates p ----
-  // Placement-independent hand-off (cdna_hip_programming.md G16, counter form with write-through stores): the
-  // partials above were stored sc1 (agent-scope atomic stores), every storing wave drains them (vmcnt(0)), barrier,
-  // then lane 0 takes a ticket with a relaxed agent-scope add; the workgroup that draws the last ticket does ONE
-  // agent-scope acquire (invalidates its L1) and reads the other workgroups' partials with plain loads.
-  if constexpr (kB) {
-    if (sa.tickets) {
-      if (blockIdx.x == 0 && threadIdx.x == 0) {
-        list_clear(sa.clr_count);
-        if (sa.count_hist) sa.count_hist[sa.level * sa.max_iter + sa.iter] = list_total(sa.cur_count);
-      }
-      int* flag = reinterpret_cast<int*>(lds);  // (the fold scratch is dead after the barrier below)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        const int ticket = __hip_atomic_fetch_add(sa.tickets + pair_slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = (ticket == ntiles - 1);
-        if (last) {
-          __hip_atomic_store(sa.tickets + pair_slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next iteration
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        *flag = last;
-      }
-      __syncthreads();
-      const bool last = *flag != 0;
-      __syncthreads();
-      if (last) solve_pair(sa, pair_slot, pair, reinterpret_cast<double*>(lds) + 8);
+      *dst = val;
     }
   }
 }

@@ -69,7 +69,7 @@ struct ica_ctx {
   // workspaces
   DevBuf pyr1[ICA_MAX_SCALES], pyr2[ICA_MAX_SCALES];  // levels >= 1
   DevBuf tmp_resample;                                // intermediate of the separable pyramid pass
-  DevBuf partials, hinv, p_prev, lambda_it, error, niter, lists, counts, count_hist, minmax, mm_part, mm_in, tickets;
+  DevBuf partials, hinv, p_prev, lambda_it, error, niter, lists, counts, count_hist, minmax, mm_part, mm_in;
   DevBuf scratch_p;
   int* pinned_count = nullptr;   // one list's shard counters for synchronous reads + a [scales][max_iter] board the kernels post to
   int* board = nullptr;          // host pointer of the board (pinned, host-coherent)
@@ -86,7 +86,7 @@ struct ica_ctx {
     for (auto e : ev_pool) (void)hipEventDestroy(e);
     for (int i = 0; i < ICA_MAX_SCALES; ++i) { pyr1[i].release(); pyr2[i].release(); }
     DevBuf* all[] = {&tmp_resample, &partials, &hinv, &p_prev, &lambda_it, &error, &niter, &lists, &counts,
-                     &count_hist, &minmax, &mm_part, &mm_in, &tickets, &scratch_p};
+                     &count_hist, &minmax, &mm_part, &mm_in, &scratch_p};
     for (auto* b : all) b->release();
     if (pinned_count) (void)hipHostFree(pinned_count);
     if (board) (void)hipHostFree(board);
@@ -289,12 +289,9 @@ int launch_pyramid_down(ica_ctx* ctx, int batch, int C, int H, int W, int h, int
 // ICA_ACCUM=1 selects the simple direct-gather kernel (kept as an in-library cross-check of the LDS-staged one)
 int g_accum_variant = 2;
 int g_fold_hessian = 1;
-int g_fuse_solve = 0;  // ICA_FUSE_SOLVE=n: fuse the per-pair solve into the iteration kernel (last-arriving tile solves)
-                      // when <= n pairs are left.  Measured slower than the separate solve kernel at every n on
-                      // configs[1] (6.41-6.55 ms vs 6.25 ms per step), so it is off by default; kept, tested, as an option.
 
 template <int TT, int MODE>
-void launch_accumulate_c(int C, dim3 grid, hipStream_t st, const LevelArgs& a, const SolveArgs& sa) {
+void launch_accumulate_c(int C, dim3 grid, hipStream_t st, const LevelArgs& a) {
   if (g_accum_variant == 1) {
     if (C == 1)
       hipLaunchKernelGGL((ica_accumulate_kernel<TT, MODE, 1>), grid, dim3(kBlock), 0, st, a);
@@ -307,31 +304,29 @@ void launch_accumulate_c(int C, dim3 grid, hipStream_t st, const LevelArgs& a, c
     LevelArgs al = a;
     al.n_pairs = (int)grid.y;  // the kernel picks the same map from it
     if (C == 1)
-      hipLaunchKernelGGL((ica_accumulate2_kernel<TT, MODE, 1>), g1, dim3(kBlock), 0, st, al, sa);
+      hipLaunchKernelGGL((ica_accumulate2_kernel<TT, MODE, 1>), g1, dim3(kBlock), 0, st, al);
     else
-      hipLaunchKernelGGL((ica_accumulate2_kernel<TT, MODE, 3>), g1, dim3(kBlock), 0, st, al, sa);
+      hipLaunchKernelGGL((ica_accumulate2_kernel<TT, MODE, 3>), g1, dim3(kBlock), 0, st, al);
   }
 }
 
 template <int MODE>
-void launch_accumulate(int tt, int C, dim3 grid, hipStream_t st, const LevelArgs& a, const SolveArgs& sa) {
+void launch_accumulate(int tt, int C, dim3 grid, hipStream_t st, const LevelArgs& a) {
   switch (tt) {
-    case ICA_TRANSLATION: launch_accumulate_c<ICA_TRANSLATION, MODE>(C, grid, st, a, sa); break;
-    case ICA_EUCLIDEAN: launch_accumulate_c<ICA_EUCLIDEAN, MODE>(C, grid, st, a, sa); break;
-    case ICA_SIMILARITY: launch_accumulate_c<ICA_SIMILARITY, MODE>(C, grid, st, a, sa); break;
-    case ICA_AFFINITY: launch_accumulate_c<ICA_AFFINITY, MODE>(C, grid, st, a, sa); break;
-    default: launch_accumulate_c<ICA_HOMOGRAPHY, MODE>(C, grid, st, a, sa); break;
+    case ICA_TRANSLATION: launch_accumulate_c<ICA_TRANSLATION, MODE>(C, grid, st, a); break;
+    case ICA_EUCLIDEAN: launch_accumulate_c<ICA_EUCLIDEAN, MODE>(C, grid, st, a); break;
+    case ICA_SIMILARITY: launch_accumulate_c<ICA_SIMILARITY, MODE>(C, grid, st, a); break;
+    case ICA_AFFINITY: launch_accumulate_c<ICA_AFFINITY, MODE>(C, grid, st, a); break;
+    default: launch_accumulate_c<ICA_HOMOGRAPHY, MODE>(C, grid, st, a); break;
   }
 }
 
-// `sa.tickets != nullptr` makes the last-arriving tile of each pair run the solve inside the same launch
-void launch_accumulate_mode(int mode, int tt, int C, dim3 grid, hipStream_t st, const LevelArgs& a,
-                            const SolveArgs& sa = SolveArgs{}) {
-  if (mode == kModeL2) launch_accumulate<kModeL2>(tt, C, grid, st, a, sa);
-  else if (mode == kModeRobust) launch_accumulate<kModeRobust>(tt, C, grid, st, a, sa);
-  else if (mode == kModeL2First && g_accum_variant == 2) launch_accumulate<kModeL2First>(tt, C, grid, st, a, sa);
-  else if (mode == kModeL2First) launch_accumulate<kModeRobust>(tt, C, grid, st, a, sa);  // v1: weights 1 at run time
-  else launch_accumulate<kModeHessian>(tt, C, grid, st, a, sa);
+void launch_accumulate_mode(int mode, int tt, int C, dim3 grid, hipStream_t st, const LevelArgs& a) {
+  if (mode == kModeL2) launch_accumulate<kModeL2>(tt, C, grid, st, a);
+  else if (mode == kModeRobust) launch_accumulate<kModeRobust>(tt, C, grid, st, a);
+  else if (mode == kModeL2First && g_accum_variant == 2) launch_accumulate<kModeL2First>(tt, C, grid, st, a);
+  else if (mode == kModeL2First) launch_accumulate<kModeRobust>(tt, C, grid, st, a);  // v1: weights 1 at run time
+  else launch_accumulate<kModeHessian>(tt, C, grid, st, a);
 }
 
 int launch_warp(ica_ctx* ctx, int batch, int C, int H, int W, int tt, const float* I2, const double* p,
@@ -372,7 +367,6 @@ int ensure_state(ica_ctx* ctx, const ica_problem* pr, const LevelGeom* g) {
   ICA_HIP(ctx, ctx->niter.ensure(B * sizeof(int)));
   ICA_HIP(ctx, ctx->lists.ensure(3 * (size_t)kListShards * list_shard_cap((int)B) * sizeof(int)));
   ICA_HIP(ctx, ctx->counts.ensure(3 * kListShards * kShardStride * sizeof(int)));
-  ICA_HIP(ctx, ctx->tickets.ensure(B * sizeof(int)));
   ICA_HIP(ctx, ctx->count_hist.ensure((size_t)pr->nscales * std::max(1, pr->max_iter) * sizeof(int)));
   ICA_HIP(ctx, ctx->minmax.ensure((size_t)pr->nscales * B * 2 * sizeof(float)));
   ICA_HIP(ctx, ctx->mm_in.ensure(B * 2 * sizeof(float)));
@@ -436,7 +430,6 @@ int ica_create(int device, ica_ctx** out) {
   auto* c = new ica_ctx();
   c->device = device;
   if (const char* e = getenv("ICA_ACCUM")) g_accum_variant = (atoi(e) == 1) ? 1 : 2;
-  if (const char* e = getenv("ICA_FUSE_SOLVE")) g_fuse_solve = atoi(e);
   if (const char* e = getenv("ICA_SEPARATE_HESSIAN")) g_fold_hessian = atoi(e) == 0;
   *out = c;
   return ICA_OK;
@@ -526,7 +519,6 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
   if (trace_out)
     ICA_HIP(ctx, hipMemsetAsync(trace_out, 0, (size_t)B * ns * max_iter * ICA_TRACE_STRIDE * sizeof(double), st));
   ICA_HIP(ctx, hipMemsetAsync(niter_out, 0, (size_t)B * ns * sizeof(int32_t), st));
-  ICA_HIP(ctx, hipMemsetAsync(ctx->tickets.ptr, 0, (size_t)B * sizeof(int), st));
 
   int* lists = ctx->lists.as<int>();
   int* counts = ctx->counts.as<int>();
@@ -621,9 +613,7 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
       sa.invert_h = robust || first_l2;  // the solve inverts the H it receives ...
       sa.store_hinv = first_l2;          // ... and keeps the inverse for the later L2 iterations
       la.robust_type = first_l2 ? (int)ICA_QUADRATIC : pr->robust_type;
-      const bool fuse = nb <= g_fuse_solve && g_accum_variant == 2;
-      sa.tickets = fuse ? ctx->tickets.as<int>() : nullptr;
-      launch_accumulate_mode(robust ? kModeRobust : first_l2 ? kModeL2First : kModeL2, tt, C, dim3(lg.tiles, nb), st, la, sa);
+      launch_accumulate_mode(robust ? kModeRobust : first_l2 ? kModeL2First : kModeL2, tt, C, dim3(lg.tiles, nb), st, la);
       if (ctx->profiling) {
         ICA_TRY(next_event(&e1));
         ICA_HIP(ctx, hipEventRecord(ctx->ev_pool[e1], st));
@@ -631,7 +621,7 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
       }
       if (first_l2) first_launches[s]++;
       else launches[s]++;
-      if (!fuse) hipLaunchKernelGGL(ica_solve_kernel, dim3(nb), dim3(kSolveThreads), 0, st, sa);
+      hipLaunchKernelGGL(ica_solve_kernel, dim3(nb), dim3(kSolveThreads), 0, st, sa);
     }
     ICA_HIP(ctx, hipGetLastError());
   }

@@ -346,7 +346,6 @@ struct SolveArgs {
   double* trace;          // nullable [B][nscales][max_iter][10]
   int invert_h;           // this launch carries H partials: invert them (robust loop; L2: first iteration of a level)
   int store_hinv;         // L2, first iteration of a level: keep inv(H) in Hinv[pair] for the next iterations
-  int* tickets;           // [B] arrival counters of the fused (last-tile-solves) mode; nullptr: separate solve kernel
 };
 
 // Sum the tile partials of one launch slot in a fixed order (deterministic): 256 threads = 4 groups x 64 lanes;
@@ -459,7 +458,7 @@ __device__ __forceinline__ bool lu_factor_wave(int n, const double* H, int ld, d
 }
 
 // Solve + compositional update + loop control for one active pair (ref :117-131 / :233-259).  Called by all 256
-// threads of a workgroup; `scratch` is kSolveScratch doubles of LDS.  `slot` indexes the launch's partials.
+// threads of a workgroup (ica_solve_kernel); `scratch` is kSolveScratch doubles of LDS.  `slot` indexes the launch's partials.
 __device__ __forceinline__ void solve_pair(const SolveArgs& a, int slot, int pair, double* scratch) {
   double* s = scratch;
   double* Hm = scratch + 5 * kAccStride;

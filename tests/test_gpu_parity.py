@@ -264,10 +264,9 @@ def test_deterministic(eng):
 
 
 def test_alternative_schedules_give_the_same_iterates(eng):
-    """The library's optional code paths are alternative schedules of the same arithmetic: the last-arriving tile
-    running the solve inside the iteration kernel (ICA_FUSE_SOLVE), a separate Hessian pass per level instead of the
-    folded first iteration (ICA_SEPARATE_HESSIAN), the direct-gather iteration kernel (ICA_ACCUM=1), 16-row tiles
-    everywhere (ICA_MAX_TILE_H).  Identical iteration counts, parameters equal to rounding -- on an L2 and on a robust
+    """The library's optional code paths are alternative schedules of the same arithmetic: a separate Hessian pass per
+    level instead of the folded first iteration (ICA_SEPARATE_HESSIAN), the direct-gather iteration kernel
+    (ICA_ACCUM=1), 16-row tiles everywhere (ICA_MAX_TILE_H).  Identical iteration counts, parameters equal to rounding -- on an L2 and on a robust
     problem (the options are read when a context is created, hence one process per setting)."""
     import os
     import subprocess
@@ -282,8 +281,7 @@ def test_alternative_schedules_give_the_same_iterates(eng):
             "np.save(sys.argv[1], np.concatenate(out))"
             % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     outs = {}
-    for name, extra in (("default", {}), ("fused_solve", {"ICA_FUSE_SOLVE": "1000"}),
-                        ("separate_hessian", {"ICA_SEPARATE_HESSIAN": "1"}), ("direct_gather", {"ICA_ACCUM": "1"}),
+    for name, extra in (("default", {}), ("separate_hessian", {"ICA_SEPARATE_HESSIAN": "1"}), ("direct_gather", {"ICA_ACCUM": "1"}),
                         ("short_tiles", {"ICA_MAX_TILE_H": "16"})):
         path = f"/tmp/ica_schedule_{name}.npy"
         subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, **extra), timeout=300)
