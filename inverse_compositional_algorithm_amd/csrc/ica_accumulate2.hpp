@@ -118,7 +118,9 @@ __device__ __forceinline__ void displacement_col(const float* A, float cx, float
 }
 
 template <int TT, int MODE, int C>
-__global__ __launch_bounds__(kBlock) void ica_accumulate2_kernel(LevelArgs a) {
+// (second launch bound = waves per SIMD the register allocator must leave room for: what the LDS footprint allows)
+// (C == 3 is LDS-limited to 4 waves and is left alone: squeezing its registers further made it 9 % slower)
+__global__ __launch_bounds__(kBlock, (C == 1 ? (TT == ICA_HOMOGRAPHY ? 5 : 6) : 1)) void ica_accumulate2_kernel(LevelArgs a) {
   constexpr int N = NP<TT>::n;
   constexpr int NT = N * (N + 1) / 2;
   constexpr bool kB = (MODE != kModeHessian);
