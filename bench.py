@@ -1,23 +1,34 @@
 #!/usr/bin/env python3
 """Benchmark of the inverse-compositional hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W            (N = 1)
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+With N > 1 and no torchrun environment, bench.py starts the N ranks itself (a child `python -m torch.distributed.run
+--nproc-per-node N bench.py ...`, started before this process touches the GPU) and relays rank 0's JSON line; under
+torchrun (RANK / WORLD_SIZE set) it is one of the ranks.  The ranks count themselves with an all-reduce and the run
+FAILS if that count differs from --gpus: an N-GPU number can never silently be a 1-GPU number.
 
 One "step" = one full pyramidal solve of a batch of synthetic warped pairs that is already resident in HBM:
 pyramid construction, per-level setup, every inverse-compositional iteration (fused warp + steepest descent +
 J^T J / J^T r kernel, then the per-pair solve/update kernel) until every pair has converged or hit MAX_ITER.
 The metric is BASELINE.json's "IC iterations/sec": executed (pair, scale, iteration) units per second, whole job.
 Pairs are independent, so N GPUs run N shards of the same per-GPU batch with no collective (weak scaling).
+
+The headline workload is BASELINE.json configs[3] (1024 pairs of 1024x1024, homography, Lorentzian, 4 scales): the
+configuration the 70 %-of-roofline target is quoted on, whose iteration kernel is the fused
+warp + steepest-descent + Hessian pass with the robust weight, `ica_accumulate2_kernel<5, 1, 1>`.  At N = 1 the same
+JSON line carries `per_config`: shorter runs of configs[1], configs[2] and the per-GPU shard of configs[4].
 """
 from __future__ import annotations
 
 import argparse
 import contextlib
-import threading
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -34,96 +45,179 @@ CONFIGS = {
     5: dict(batch=1024, H=1080, W=1920, C=3, transform=5, robust=3, nscales=5,
             name="configs[4]: 1024 pairs/GPU 1920x1080x3, HOMOGRAPHY, LORENTZIAN, 5 scales"),
 }
+DEFAULT_CONFIG = 4                 # BASELINE configs[3]
+SIDE_CONFIGS = ((2, 3), (3, 3), (5, 2))   # (config id, timed steps) of the per_config entries
+SIDE_DEADLINE_S = 330.0            # no side config is started later than this after process start
 IN_FLIGHT_DEFAULT = 1
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+TNAME = {1: "TRANSLATION", 2: "EUCLIDEAN", 3: "SIMILARITY", 4: "AFFINITY", 5: "HOMOGRAPHY"}
+T_START = time.perf_counter()
 
 
-def measured_traffic_ratio():
-    """HBM bytes / algorithmic bytes of the fused iteration kernel, from the committed PMC run
-    (profiles/r01_traffic.json: rocprofv3 --pmc FETCH_SIZE, x1024 B, x2 gfx950 correction).  bench.py cannot collect
-    PMC counters itself; the per-launch `traffic` it reports is this measured ratio times the launch's algorithmic bytes."""
+def kernel_key(cfg):
+    """Template arguments <transform, mode, channels> of the steady-state iteration kernel of a workload."""
+    return f"<{cfg['transform']}, {1 if cfg['robust'] else 0}, {cfg['C']}>"
+
+
+def measured_traffic(cfg):
+    """HBM bytes / algorithmic bytes of one full-batch launch of this workload's iteration kernel, from the committed
+    PMC passes (profiles/r02_traffic.json, built by tools/pmc_traffic.sh from the raw rocprofv3 --pmc FETCH_SIZE CSVs
+    next to it; x1024 B, x2 gfx950 correction).  bench.py cannot collect PMC counters itself: the per-launch `traffic`
+    it reports is this measured ratio times the launch's algorithmic bytes; null when no pass exists for the kernel."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
-            return float(json.load(fh)["fetch_bytes_over_algorithmic_bytes"])
+        with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as fh:
+            e = json.load(fh)["kernels"][kernel_key(cfg)]
+        return float(e["fetch_bytes_over_algorithmic_bytes"]), e.get("source")
     except Exception:
-        return None
+        return None, None
 
 
-def cpu_baseline(cfg, seconds_budget=15.0):
-    """The oracle (float64 NumPy restatement with the reference's structure) on a bounded sample of the same
-    workload, timed on this host.  Reported next to the GPU number; it is never the thing measured as `value`."""
+def host_info():
+    info = {"nproc": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)),
+            "OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS"), "MKL_NUM_THREADS": os.environ.get("MKL_NUM_THREADS")}
+    try:
+        from threadpoolctl import threadpool_info
+        info["blas"] = [{k: d.get(k) for k in ("internal_api", "num_threads")} for d in threadpool_info()]
+    except Exception:
+        info["blas"] = None
+    return info
+
+
+def cpu_baseline(cfg, mean_iters_per_scale, budget_s=30.0):
+    """The oracle (float64 NumPy restatement with the reference's structure) timed on this host on a BOUNDED sample of
+    the same workload: ONE pair; at every pyramid scale the per-level setup of `oracle.ica_single_scale` (gradient,
+    Jacobian, steepest-descent tensor, L2 Hessian: ref :81-103 / :200-218) and K = 2 passes of its loop body (warp,
+    residual, rho', J^T r, J^T J, inverse, solve, update: ref :109-131 / :225-259) are timed, and both are
+    extrapolated to the mean iteration counts per scale the GPU run executed.  It is reported next to the GPU
+    number; it is never the thing measured as `value`."""
     import numpy as np
     from inverse_compositional_algorithm_amd import synthetic as syn
     from oracle import ica_oracle as oc
-    n = oc.nparams(cfg["transform"])
-    iters, pairs, t_total = 0, 0, 0.0
-    while t_total < seconds_budget and pairs < 64:
-        I1, I2, _ = syn.make_pair(1000 * 2 + pairs, cfg["H"], cfg["W"], cfg["C"], cfg["transform"],
-                                  robust_clutter=cfg["robust"] != 0)
-        I1, I2 = I1.astype(np.float64), I2.astype(np.float64)
+    t, rt, ns = cfg["transform"], cfg["robust"], cfg["nscales"]
+    n = oc.nparams(t)
+    I1, I2, p_gt = syn.make_pair(1000 * 2, cfg["H"], cfg["W"], cfg["C"], t, robust_clutter=rt != 0)
+    L1, L2 = [I1.astype(np.float64)], [I2.astype(np.float64)]
+    t0 = time.perf_counter()
+    for s in range(1, ns):
+        L1.append(oc.rescale_restated(L1[-1], 0.5))
+        L2.append(oc.rescale_restated(L2[-1], 0.5))
+    t_pyr = time.perf_counter() - t0
+    setup, per_iter, spent, K = [0.0] * ns, [0.0] * ns, t_pyr, 2
+    for s in range(ns - 1, -1, -1):   # coarse to fine; the fine scales are the expensive ones
+        if spent > budget_s:  # out of budget: extrapolate the remaining (finer) scales by pixel count
+            per_iter[s], setup[s] = per_iter[s + 1] * 4.0, setup[s + 1] * 4.0
+            continue
+        ny, nx = L1[s].shape[:2]
+        p = 0.9 * np.asarray(p_gt, dtype=np.float64)  # a mid-trajectory iterate: the ground truth at this level, scaled
+        if t == oc.HOMOGRAPHY:
+            p[[2, 5]] *= 0.5 ** s
+            p[[6, 7]] /= 0.5 ** s
+        else:
+            p[:2] *= 0.5 ** s
         t0 = time.perf_counter()
-        _, _, _, _, nit = oc.ica_pyramidal(I1, I2, np.zeros(n), cfg["transform"], cfg["nscales"], 0.5, 1e-3,
-                                           cfg["robust"], 0.0, True, 10)
-        t_total += time.perf_counter() - t0
-        iters += sum(nit)
-        pairs += 1
-    return {"value": iters / t_total, "unit": "pair-iterations/s", "cores": 1, "kind": "port",
-            "sample": f"{pairs} pairs of the same workload ({iters} pair-iterations, {t_total:.1f} s), oracle/ica_oracle.py "
-                      f"(float64 NumPy, materialised steepest-descent tensor + einsum, as the reference)",
-            "pairs_per_s": pairs / t_total}
+        Ix, Iy = oc.gradient(L1[s], True, 10)
+        J = oc.jacobian(t, nx, ny)
+        DIJ = oc.steepest_descent_images(Ix, Iy, J, n)
+        if rt == oc.QUADRATIC:
+            H_1 = oc.inverse_hessian(oc.hessian(DIJ))
+        setup[s] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for _ in range(K):
+            Iw = oc.warp_params(L2[s], p, t)
+            DI = Iw - L1[s]
+            if rt != oc.QUADRATIC:
+                rho = oc.robust_error_function(DI, 40.0, rt)
+                b = oc.independent_vector(DIJ, DI, rho)
+                H_1 = oc.inverse_hessian(oc.hessian(DIJ, rho))
+            else:
+                b = oc.independent_vector(DIJ, DI)
+            _, dp = oc.parametric_solve(H_1, b)
+            oc.update_transform(p.copy(), dp, t)
+        per_iter[s] = (time.perf_counter() - t0) / K
+        spent += setup[s] + K * per_iter[s]
+        del DIJ, J, Ix, Iy
+    iters = sum(mean_iters_per_scale)
+    t_pair = t_pyr + sum(setup[s] + mean_iters_per_scale[s] * per_iter[s] for s in range(ns))
+    return {"value": iters / t_pair, "unit": "pair-iterations/s", "cores": 1, "kind": "port",
+            "sample": f"1 pair of the same workload; per pyramid scale the level setup and {K} passes of the loop body of "
+                      f"oracle.ica_single_scale ({spent:.1f} s of CPU work), extrapolated to the GPU run's mean iterations "
+                      f"per scale {[round(v, 2) for v in mean_iters_per_scale]}; oracle/ica_oracle.py = float64 NumPy, "
+                      f"materialised steepest-descent tensor + einsum, as the reference",
+            "pairs_per_s": 1.0 / t_pair, "seconds_per_iteration_by_scale": per_iter, "setup_seconds_by_scale": setup,
+            "pyramid_seconds": t_pyr, "host": host_info()}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
-    ap.add_argument("--batch", type=int, default=0, help="pairs per GPU (default: the config's)")
-    ap.add_argument("--in-flight", type=int, default=IN_FLIGHT_DEFAULT,
-                    help="solves kept in flight per GPU (one engine + HIP stream + host thread each): the straggler "
-                         "launches of one solve overlap the pyramid and coarse levels of the next")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+# ---- launching the ranks -----------------------------------------------------------------------------------
 
+def spawn_ranks(n, argv):
+    """Start the N ranks as a CHILD process (nothing in this process has touched the GPU yet; no exec of a
+    GPU-initialised process) and exit with its code.  The child's rank 0 prints the JSON line on our stdout."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+class StubEngine:
+    """CPU stand-in for the engine (BENCH_STUB=1): lets the launcher, the rank count check and the aggregation be
+    tested with gloo on a machine without a GPU.  It computes nothing and is never used for a reported number."""
+
+    def __init__(self):
+        import torch
+        self.device = torch.device("cpu")
+
+
+def run_stub(args, info, sharding):
     import torch
+    eng = StubEngine()
+    sharding.barrier(info, eng.device)
+    t0 = time.perf_counter()
+    time.sleep(0.01 * args.steps)
+    units = 100.0 * args.steps * (info.rank + 1)
+    sharding.barrier(info, eng.device)
+    dt = time.perf_counter() - t0
+    dt, units_all, pairs_all = sharding.aggregate(info, dt, units, 8.0 * args.steps, eng.device)
+    return dict(dt=dt, units_all=units_all, pairs_all=pairs_all)
 
-    from inverse_compositional_algorithm_amd import sharding
-    info = sharding.rank_info()
-    world, rank, local = info.world, info.rank, info.local_rank
-    if world > 1:
-        torch.cuda.set_device(local)
-    sharding.init("nccl", info)  # backend "nccl" is RCCL on ROCm; used for the barrier and 3 scalars only
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
+# ---- one measured workload ---------------------------------------------------------------------------------
+
+def measure(args, info, sharding, cfg_id, steps, warmup, D, batch=0):
+    """Generate this rank's shard of `cfg_id`, run `warmup` untimed and `steps` timed solves between barriers.
+    Returns this job's aggregate numbers (all ranks) and rank-local quality figures."""
+    import torch
     from inverse_compositional_algorithm_amd.engine import IcaEngine
-    cfg = dict(CONFIGS[args.config])
-    if args.batch:
-        cfg["batch"] = args.batch
-    eng = IcaEngine(local)
+    local = info.local_rank
+    cfg = dict(CONFIGS[cfg_id])
+    if batch:
+        cfg["batch"] = batch
     torch.cuda.set_device(local)
+    eng = IcaEngine(local)
     B, H, W, C = cfg["batch"], cfg["H"], cfg["W"], cfg["C"]
     # each rank owns its own shard of pairs, generated on its own device (no host staging, no exchange)
-    I1, I2, p_gt = eng.make_batch(sharding.shard_seed(args.config, rank), B, H, W, C, cfg["transform"],
+    t_gen = time.perf_counter()
+    I1, I2, p_gt = eng.make_batch(sharding.shard_seed(cfg_id, info.rank), B, H, W, C, cfg["transform"],
                                   robust_clutter=cfg["robust"] != 0)
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t_gen
     prob = eng.problem(B, H, W, C, cfg["transform"], cfg["robust"], nscales=cfg["nscales"], nu=0.5, tol=1e-3,
                        lambda_=0.0, nanifoutside=True, delta=10)
     eng.prepare(prob)
-    # HIP events around every fused-iteration launch, on the stream it runs on.  ~90 event pairs per solve cost 0.3 ms
-    # of a 5.4 ms step (measured: BENCH_EVENTS=all vs none), so they bracket every 5th timed step (step 0, 5, ...):
-    # the roofline figures are live measurements inside the timed region, taken on that sample of its steps.
+    # HIP events around every fused-iteration launch, on the stream it runs on.  Event pairs cost GPU time (~3.4 us
+    # each), so they bracket every 5th timed step (step 0, 5, ...): the roofline figures are live measurements inside
+    # the timed region, taken on that sample of its steps.
     ev_mode = os.environ.get("BENCH_EVENTS", "sample")  # sample | all | none
+
     def profiled(i):
         return ev_mode == "all" or (ev_mode == "sample" and i % 5 == 0)
-
-    def barrier():
-        sharding.barrier(info, eng.device)
 
     # D solves in flight: D engines (own workspaces, own HIP stream, own host thread -- the host follows each solve to
     # size its launches), all reading the same resident batch.  Steps are handed out one by one, so exactly
     # `steps` solves run between the two barriers however they interleave.
-    D = max(1, args.in_flight)
     engines = [eng] + [IcaEngine(local) for _ in range(D - 1)]
     for e in engines[1:]:
         e.prepare(prob)
@@ -159,8 +253,9 @@ def main():
 
     gate = Gate()
     errors = []
-    acc = dict(units=0, dom_ms=0.0, dom_bytes=0.0, dom_n=0, s0_ms=0.0, s0_bytes=0.0, first_ms=0.0, n_prof=0, res=None,
-               latency=0.0)
+    ns = cfg["nscales"]
+    acc = dict(units=0, per_scale=[0] * ns, dom_ms=0.0, dom_bytes=0.0, dom_n=0, s0_ms=0.0, s0_bytes=0.0, s0_n=0,
+               first_ms=0.0, n_prof=0, res=None, latency=0.0)
 
     def run_steps(n_steps, timed):
         counter = iter(range(n_steps))
@@ -192,6 +287,8 @@ def main():
                         continue
                     with lock:
                         acc["units"] += r.stats["pair_iterations_total"]
+                        for s in range(ns):
+                            acc["per_scale"][s] += r.stats["pair_iterations"][s]
                         acc["latency"] += t_e - t_s
                         acc["res"] = r
                         if prof:
@@ -201,6 +298,7 @@ def main():
                             acc["dom_n"] += sum(r.stats["iter_launches"])
                             acc["s0_ms"] += r.stats["iter_kernel_ms"][0]
                             acc["s0_bytes"] += r.stats["iter_kernel_bytes"][0]
+                            acc["s0_n"] += r.stats["iter_launches"][0]
                             acc["first_ms"] += sum(r.stats["first_kernel_ms"])
 
         if D == 1:
@@ -216,72 +314,168 @@ def main():
 
     # the dominant kernel = the steady-state iteration kernel (one template instantiation), ALL its launches of the
     # event-bracketed steps at every pyramid scale -- the same set rocprofv3 --stats averages under that kernel's name
-    run_steps(max(args.warmup, D if D > 1 else 0), timed=False)
-    barrier()
+    run_steps(max(warmup, D if D > 1 else 0), timed=False)
+    sharding.barrier(info, eng.device)
     t0 = time.perf_counter()
-    run_steps(args.steps, timed=True)
-    barrier()
+    run_steps(steps, timed=True)
+    sharding.barrier(info, eng.device)
     dt = time.perf_counter() - t0
-    units, res, n_prof = acc["units"], acc["res"], acc["n_prof"]
-    dom_ms, dom_bytes, dom_n = acc["dom_ms"], acc["dom_bytes"], acc["dom_n"]
-    s0_ms, s0_bytes, first_ms = acc["s0_ms"], acc["s0_bytes"], acc["first_ms"]
+    res = acc["res"]
 
     # solution quality on this shard (not part of the timed region)
     n = eng.lib.ica_nparams(cfg["transform"])
     perr = (res.p[:, :n] - p_gt[:, :n]).abs().amax(dim=1)
     converged = float((res.error < 1e-3).double().mean())
+    hit_cap = float((res.niter >= 30).any(dim=1).double().mean())
+    dt, units_all, pairs_all = sharding.aggregate(info, dt, float(acc["units"]), float(B * steps), eng.device)
 
-    dt, units_all, pairs_all = sharding.aggregate(info, dt, float(units), float(B * args.steps), eng.device)
+    dom_ms, dom_bytes, dom_n, n_prof = acc["dom_ms"], acc["dom_bytes"], acc["dom_n"], acc["n_prof"]
+    ms_per_step = dt / steps * 1e3
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    ratio, src = measured_traffic(cfg)
+    out = dict(
+        cfg=cfg, dt=dt, units_all=units_all, pairs_all=pairs_all, ms_per_step=ms_per_step,
+        step_latency_ms=acc["latency"] / max(steps, 1) * 1e3, gen_seconds=t_gen,
+        mean_iters_per_scale=[acc["per_scale"][s] / float(B * steps) for s in range(ns)],
+        roofline={
+            "bound": "hbm",
+            "kernel": f"ica_accumulate2_kernel{kernel_key(cfg)} ({TNAME[cfg['transform']]}, "
+                      f"{'robust: H+b every iteration' if cfg['robust'] else 'L2: b only, iterations >= 1'}), "
+                      "all its launches of the event-bracketed steps at all scales (grids shrink as pairs converge)",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": (ratio * dom_bytes / max(dom_n, 1)) if ratio else None,
+            "traffic_source": src,
+            "algorithmic_bytes_per_launch": dom_bytes / max(dom_n, 1),
+            "avg_launch_ms": dom_ms / max(dom_n, 1), "launches": dom_n, "event_bracketed_steps": n_prof,
+            "kernel_share_of_step": dom_ms / max(n_prof, 1) / ms_per_step,
+            "scale0": {"GBps": (acc["s0_bytes"] / (acc["s0_ms"] * 1e-3) / 1e9) if acc["s0_ms"] > 0 else None,
+                       "frac": (acc["s0_bytes"] / (acc["s0_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if acc["s0_ms"] > 0 else None,
+                       "avg_launch_ms": acc["s0_ms"] / max(acc["s0_n"], 1), "launches": acc["s0_n"]},
+            "first_iteration_kernel_share_of_step": acc["first_ms"] / max(n_prof, 1) / ms_per_step,
+            "bytes_per_element_convention": 4,
+        },
+        quality={"converged_frac": converged, "hit_iteration_cap_frac": hit_cap,
+                 "median_abs_param_err_vs_gt": float(perr.median()), "mean_iters_per_pair": units_all / pairs_all},
+    )
+    del I1, I2, p_gt, res
+    for e in engines:
+        e.close()
+    torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", type=int, default=DEFAULT_CONFIG, choices=sorted(CONFIGS),
+                    help="2..5 = BASELINE.json configs[1..4]; default 4 = configs[3], the headline workload")
+    ap.add_argument("--batch", type=int, default=0, help="pairs per GPU (default: the config's)")
+    ap.add_argument("--in-flight", type=int, default=IN_FLIGHT_DEFAULT,
+                    help="solves kept in flight per GPU (one engine + HIP stream + host thread each): the straggler "
+                         "launches of one solve overlap the pyramid and coarse levels of the next")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-per-config", action="store_true", help="skip the per_config side measurements (N = 1 only)")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves, before anything here touches the GPU
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+
+    import torch
+
+    from inverse_compositional_algorithm_amd import sharding
+    stub = os.environ.get("BENCH_STUB") == "1"
+    info = sharding.rank_info()
+    world, rank, local = info.world, info.rank, info.local_rank
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing to report a "
+              f"number for a job of another size", file=sys.stderr)
+        sys.exit(2)
+    if world > 1 and not stub:
+        torch.cuda.set_device(local)
+    sharding.init("gloo" if stub else "nccl", info)  # backend "nccl" is RCCL on ROCm; barrier + 3 scalars only
+    dev = torch.device("cpu") if stub else torch.device("cuda", local)
+    n_ranks = sharding.count_ranks(info, dev)  # every rank contributes a 1: what the collective library really spans
+    if n_ranks != args.gpus:
+        print(f"bench.py: the ranks count {n_ranks} of themselves, --gpus says {args.gpus}", file=sys.stderr)
+        sharding.finalize(info)
+        sys.exit(3)
+
+    if stub:
+        r = run_stub(args, info, sharding)
+        if rank == 0:
+            print(json.dumps({"metric": "IC iterations/sec", "value": r["units_all"] / r["dt"], "unit": "pair-iterations/s",
+                              "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup, "stub": True,
+                              "units": r["units_all"], "pairs": r["pairs_all"]}))
+        sharding.finalize(info)
+        return
+
+    D = max(1, args.in_flight)
+    m = measure(args, info, sharding, args.config, args.steps, args.warmup, D, args.batch)
+    cfg = m["cfg"]
+
+    per_config = None
+    if world == 1 and not args.no_per_config and not args.batch:
+        per_config = []
+        for cid, steps in SIDE_CONFIGS:
+            if cid == args.config:
+                continue
+            if time.perf_counter() - T_START > SIDE_DEADLINE_S:
+                per_config.append({"workload": CONFIGS[cid]["name"], "skipped": "time budget of the default run"})
+                continue
+            try:
+                s = measure(args, info, sharding, cid, steps, 1, 1)
+            except Exception as exc:  # a side measurement must never cost the headline line
+                per_config.append({"workload": CONFIGS[cid]["name"], "error": repr(exc)[:200]})
+                continue
+            per_config.append({"workload": s["cfg"]["name"], "value": s["units_all"] / s["dt"], "unit": "pair-iterations/s",
+                               "steps": steps, "warmup": 1, "ms_per_step": s["ms_per_step"],
+                               "image_pairs_per_s": s["pairs_all"] / s["dt"],
+                               "roofline": {k: s["roofline"][k] for k in ("kernel", "achieved", "frac", "avg_launch_ms",
+                                                                          "launches", "traffic", "algorithmic_bytes_per_launch",
+                                                                          "scale0")},
+                               "converged_frac": s["quality"]["converged_frac"],
+                               "hit_iteration_cap_frac": s["quality"]["hit_iteration_cap_frac"],
+                               "mean_iters_per_pair": s["quality"]["mean_iters_per_pair"]})
 
     if rank == 0:
-        # the PMC pass was taken on the configs[1] kernel; other workloads report no traffic figure
-        ratio = measured_traffic_ratio() if args.config == 2 else None
-        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        tname = {1: "TRANSLATION", 2: "EUCLIDEAN", 3: "SIMILARITY", 4: "AFFINITY", 5: "HOMOGRAPHY"}[cfg["transform"]]
         out = {
             "metric": "IC iterations/sec",
-            "value": units_all / dt,
+            "value": m["units_all"] / m["dt"],
             "unit": "pair-iterations/s",
-            "n_gpus": world,
+            "n_gpus": n_ranks,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step": m["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": cfg["name"], "pairs_per_gpu": B, "height": H, "width": W, "channels": C,
-                       "transform": tname, "robust_type": cfg["robust"], "nscales": cfg["nscales"], "tol": 1e-3,
-                       "delta": 10, "parallelism": f"{world} x independent pair shards (no collective)"
-                       + (f", {D} solves in flight per GPU" if D > 1 else ""), "in_flight": D},
-            "step_latency_ms": acc["latency"] / max(args.steps, 1) * 1e3,
-            "image_pairs_per_s": pairs_all / dt,
-            "pair_iterations_per_step": units_all / args.steps,
-            "roofline": {
-                "bound": "hbm",
-                "kernel": f"ica_accumulate2_kernel<{cfg['transform']}, {1 if cfg['robust'] else 0}, {C}> "
-                          f"({tname}, {'robust: H+b every iteration' if cfg['robust'] else 'L2: b only, iterations >= 1'}), "
-                          "all its launches of the timed steps at all scales (grids shrink as pairs converge)",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": (ratio * dom_bytes / max(dom_n, 1)) if ratio else None,
-                "traffic_source": "profiles/r01_traffic.json (PMC FETCH_SIZE of this kernel at full batch)" if ratio else None,
-                "algorithmic_bytes_per_launch": dom_bytes / max(dom_n, 1),
-                "avg_launch_ms": dom_ms / max(dom_n, 1),
-                "launches": dom_n,
-                "event_bracketed_steps": n_prof,
-                "kernel_share_of_step": dom_ms / max(n_prof, 1) / (dt / args.steps * 1e3),
-                "scale0_only_GBps": (s0_bytes / (s0_ms * 1e-3) / 1e9) if s0_ms > 0 else None,
-                "first_iteration_kernel_share_of_step": first_ms / max(n_prof, 1) / (dt / args.steps * 1e3),
-            },
-            "quality": {"converged_frac": converged, "median_abs_param_err_vs_gt": float(perr.median()),
-                        "mean_iters_per_pair": units_all / pairs_all},
+            "config": {"workload": cfg["name"], "pairs_per_gpu": cfg["batch"], "height": cfg["H"], "width": cfg["W"],
+                       "channels": cfg["C"], "transform": TNAME[cfg["transform"]], "robust_type": cfg["robust"],
+                       "nscales": cfg["nscales"], "tol": 1e-3, "delta": 10,
+                       "parallelism": f"{n_ranks} x independent pair shards (no collective)"
+                       + (f", {D} solves in flight per GPU" if D > 1 else ""), "in_flight": D,
+                       "note": "synthetic pairs: multi-octave noise texture, ground-truth transform of a few percent, "
+                               "robust workloads add sigma=5 noise and a 10 % occluder; pairs that exhaust the 30 "
+                               "iterations of a scale (quality.hit_iteration_cap_frac) keep iterating like in the reference"},
+            "step_latency_ms": m["step_latency_ms"],
+            "image_pairs_per_s": m["pairs_all"] / m["dt"],
+            "pair_iterations_per_step": m["units_all"] / args.steps,
+            "mean_iters_per_scale": m["mean_iters_per_scale"],
+            "roofline": m["roofline"],
+            "quality": m["quality"],
         }
+        if per_config is not None:
+            out["per_config"] = per_config
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg)
+            out["cpu_baseline"] = cpu_baseline(cfg, m["mean_iters_per_scale"])
+        out["wall_seconds_total"] = time.perf_counter() - T_START
         print(json.dumps(out))
     sharding.finalize(info)
 

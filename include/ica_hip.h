@@ -33,6 +33,7 @@ extern "C" {
 #define ICA_ABI_VERSION 1
 #define ICA_MAX_PARAMS 8
 #define ICA_MAX_SCALES 16
+#define ICA_MAX_CHANNELS 4
 #define ICA_TRACE_STRIDE 10 /* per iteration: |dp|, p[0..7], lambda */
 
 typedef enum ica_status {
@@ -69,7 +70,8 @@ enum {
 typedef struct ica_problem {
   int32_t batch;          /* B independent image pairs                                                  */
   int32_t height, width;  /* level-0 size                                                               */
-  int32_t channels;       /* 1 or 3 (the reference accepts 3 only, ref :48)                             */
+  int32_t channels;       /* 1..ICA_MAX_CHANNELS (L2 / pyramidal reference entries accept 3 only, ref :48;   */
+                          /* its robust entry any count, ref :168-177); 1 and 3 run the LDS-staged kernel    */
   int32_t transform_type; /* ica_transform                                                              */
   int32_t robust_type;    /* ica_robust; QUADRATIC selects the L2 loop (ref :343-355)                   */
   int32_t nscales;        /* pyramid levels, >= 1 (config.ini pyramid_levels)                           */

@@ -7,6 +7,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <thread>
+#include <sched.h>
 #include <map>
 #include <string>
 #include <utility>
@@ -64,7 +67,13 @@ struct LevelGeom {
 struct ica_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipEvent_t handover = nullptr;   // orders a newly bound stream behind the work queued on the previous one
   bool profiling = false;
+  // switches read once, when the context is created; per context, not per process
+  int accum_variant = 2;           // ICA_ACCUM=1: the direct-gather iteration kernel (in-library cross-check)
+  bool fold_hessian = true;        // ICA_SEPARATE_HESSIAN=1: separate L2 Hessian pass per level
+  int max_tile_h = 512;            // ICA_MAX_TILE_H
+  double board_timeout_s = 10.0;   // ICA_BOARD_TIMEOUT_MS: how long the host waits for an iteration's count
   std::string last_error;
   // workspaces
   DevBuf pyr1[ICA_MAX_SCALES], pyr2[ICA_MAX_SCALES];  // levels >= 1
@@ -84,6 +93,7 @@ struct ica_ctx {
       delete kv.second;
     }
     for (auto e : ev_pool) (void)hipEventDestroy(e);
+    if (handover) (void)hipEventDestroy(handover);
     for (int i = 0; i < ICA_MAX_SCALES; ++i) { pyr1[i].release(); pyr2[i].release(); }
     DevBuf* all[] = {&tmp_resample, &partials, &hinv, &p_prev, &lambda_it, &error, &niter, &lists, &counts,
                      &count_hist, &minmax, &mm_part, &mm_in, &scratch_p};
@@ -112,7 +122,7 @@ namespace {
 
 int validate(const ica_problem* pr) {
   if (!pr) return ICA_EINVAL_ARG;
-  if (pr->channels != 1 && pr->channels != 3) return ICA_EINVAL_SHAPE;
+  if (pr->channels < 1 || pr->channels > ICA_MAX_CHANNELS) return ICA_EINVAL_SHAPE;
   if (pr->batch <= 0 || pr->height <= 0 || pr->width <= 0) return ICA_EINVAL_ARG;
   if (!(pr->tol < 0.01)) return ICA_EINVAL_TOL;  // ref :59-60
   if (nparams_of(pr->transform_type) < 0) return ICA_EINVAL_TRANSFORM;
@@ -125,10 +135,9 @@ int validate(const ica_problem* pr) {
 // Tile height for a launch over `pairs` pairs: the tallest tile (taller tiles amortise the per-tile fold) that still
 // gives the launch >= ~4 workgroups per CU.  Late iterations, when only a few pairs are still iterating, therefore
 // use short tiles and spread those pairs over the whole chip instead of running 16 long workgroups per pair.
-void set_tiling(LevelGeom& g, int pairs) {
+void set_tiling(LevelGeom& g, int pairs, int max_tile_h) {
   g.tiles_x = (g.W + kTileW - 1) / kTileW;
-  int th = 512;   // (at most 64 chunks of 16 rows per tile: one lane plans one chunk)
-  if (const char* e = getenv("ICA_MAX_TILE_H")) th = std::max(16, atoi(e));
+  int th = std::max(16, std::min(512, max_tile_h));   // (at most 64 chunks of 16 rows per tile: one lane plans one chunk)
   while (th > 16) {
     const long blocks = (long)pairs * g.tiles_x * ((g.H + th - 1) / th);
     if (blocks >= 2048 && th <= std::max(16, g.H)) break;
@@ -139,14 +148,14 @@ void set_tiling(LevelGeom& g, int pairs) {
   g.tiles = g.tiles_x * g.tiles_y;
 }
 
-void level_sizes(const ica_problem* pr, LevelGeom* g) {
+void level_sizes(const ica_ctx* ctx, const ica_problem* pr, LevelGeom* g) {
   g[0].W = pr->width;
   g[0].H = pr->height;
   for (int s = 1; s < pr->nscales; ++s) {  // zoom.py:8-22
     g[s].W = std::max(1, round_half_even(g[s - 1].W * pr->nu));
     g[s].H = std::max(1, round_half_even(g[s - 1].H * pr->nu));
   }
-  for (int s = 0; s < pr->nscales; ++s) set_tiling(g[s], pr->batch);
+  for (int s = 0; s < pr->nscales; ++s) set_tiling(g[s], pr->batch, ctx->max_tile_h);
 }
 
 int get_op(ica_ctx* ctx, int n_in, int n_out, DeviceBandOp** out) {
@@ -239,10 +248,7 @@ int launch_pyramid_down(ica_ctx* ctx, int batch, int C, int H, int W, int h, int
   ICA_TRY(get_op(ctx, H, h, &oy));
   const int planes = batch * C;
   const size_t lds = (size_t)kRowsH * ox->span_pad * sizeof(float);
-  if (lds > 64 * 1024 || oy->vspan_max > kVWin) {
-    ctx->last_error = "pyramid step: downsampling factor too large for the tiled resampling passes";
-    return ICA_EINVAL_ARG;
-  }
+  const bool generic_v = oy->vspan_max > kVWin, generic_h = lds > 64 * 1024;
   ICA_HIP(ctx, ctx->tmp_resample.ensure((size_t)planes * h * W * sizeof(float)));
   float* tmp = ctx->tmp_resample.as<float>();
   // 16-byte loads per lane in the vertical pass when rows and base pointers are 16-byte aligned, else 4-byte ones
@@ -250,7 +256,7 @@ int launch_pyramid_down(ica_ctx* ctx, int batch, int C, int H, int W, int h, int
   const int vgroups = (h + kOutsV - 1) / kOutsV, xblocks = vec4 ? (W + 255) / 256 : (W + 63) / 64;
   const int per_pair = C * vgroups * xblocks;  // min/max partials per pair written by the vertical pass
   float* part = nullptr;
-  if (oy->vcover) {
+  if (oy->vcover && !generic_v) {
     ICA_HIP(ctx, ctx->mm_part.ensure((size_t)batch * per_pair * 2 * sizeof(float)));
     part = ctx->mm_part.as<float>();
   } else {
@@ -262,7 +268,11 @@ int launch_pyramid_down(ica_ctx* ctx, int batch, int C, int H, int W, int h, int
     const int np = std::min(step, planes - p0);
     const dim3 gv(xblocks, (vgroups + kWaves - 1) / kWaves, np);
     float* pp = part ? part + (size_t)p0 * vgroups * xblocks * 2 : nullptr;
-    if (vec4)
+    if (generic_v)  // very small nu: window of 16 outputs wider than the tiled pass is sized for
+      hipLaunchKernelGGL(ica_resample_generic_kernel<true>, dim3((W + kBlock - 1) / kBlock, h, np), dim3(kBlock), 0,
+                         ctx->stream, in + (size_t)p0 * H * W, tmp + (size_t)p0 * h * W, C, W, oy->view(),
+                         (const float*)nullptr);
+    else if (vec4)
       hipLaunchKernelGGL(ica_resample_v_kernel<4>, gv, dim3(kBlock), 0, ctx->stream, in + (size_t)p0 * H * W,
                          tmp + (size_t)p0 * h * W, np, C, W, oy->view(), pp);
     else
@@ -275,7 +285,11 @@ int launch_pyramid_down(ica_ctx* ctx, int batch, int C, int H, int W, int h, int
   for (int p0 = 0; p0 < planes; p0 += step) {
     const int np = std::min(step, planes - p0);
     const dim3 gh((w + 63) / 64, (h + kRowsH - 1) / kRowsH, np);
-    if (W % 2 == 0)  // rows of the intermediate image are 8-byte aligned: stage with 8-byte loads
+    if (generic_h)
+      hipLaunchKernelGGL(ica_resample_generic_kernel<false>, dim3((w + kBlock - 1) / kBlock, h, np), dim3(kBlock), 0,
+                         ctx->stream, tmp + (size_t)p0 * h * W, out + (size_t)p0 * h * w, C, h, ox->view(),
+                         mm_out + (size_t)(p0 / C) * 2);
+    else if (W % 2 == 0)  // rows of the intermediate image are 8-byte aligned: stage with 8-byte loads
       hipLaunchKernelGGL(ica_resample_h_kernel<true>, gh, dim3(kBlock), lds, ctx->stream, tmp + (size_t)p0 * h * W,
                          out + (size_t)p0 * h * w, np, C, h, ox->view(), mm_out + (size_t)(p0 / C) * 2, ox->span_pad);
     else
@@ -286,17 +300,18 @@ int launch_pyramid_down(ica_ctx* ctx, int batch, int C, int H, int W, int h, int
   return ICA_OK;
 }
 
-// ICA_ACCUM=1 selects the simple direct-gather kernel (kept as an in-library cross-check of the LDS-staged one)
-int g_accum_variant = 2;
-int g_fold_hessian = 1;
-
+// variant 1 (ICA_ACCUM=1) is the simple direct-gather kernel, kept as an in-library cross-check of the LDS-staged one
 template <int TT, int MODE>
-void launch_accumulate_c(int C, dim3 grid, hipStream_t st, const LevelArgs& a) {
-  if (g_accum_variant == 1) {
-    if (C == 1)
-      hipLaunchKernelGGL((ica_accumulate_kernel<TT, MODE, 1>), grid, dim3(kBlock), 0, st, a);
-    else
-      hipLaunchKernelGGL((ica_accumulate_kernel<TT, MODE, 3>), grid, dim3(kBlock), 0, st, a);
+void launch_accumulate_c(int variant, int C, dim3 grid, hipStream_t st, const LevelArgs& a) {
+  // 1 and 3 channels (gray / RGB, the reference's data) run the LDS-staged kernel; 2 and 4 channels (the reference's
+  // robust entry point takes any channel count, ref :168-177) run the direct-gather kernel
+  if (variant == 1 || C == 2 || C == 4) {
+    switch (C) {
+      case 1: hipLaunchKernelGGL((ica_accumulate_kernel<TT, MODE, 1>), grid, dim3(kBlock), 0, st, a); break;
+      case 2: hipLaunchKernelGGL((ica_accumulate_kernel<TT, MODE, 2>), grid, dim3(kBlock), 0, st, a); break;
+      case 3: hipLaunchKernelGGL((ica_accumulate_kernel<TT, MODE, 3>), grid, dim3(kBlock), 0, st, a); break;
+      default: hipLaunchKernelGGL((ica_accumulate_kernel<TT, MODE, 4>), grid, dim3(kBlock), 0, st, a); break;
+    }
   } else {
     // 1-D grid: (pairs rounded up to a multiple of 8) x tiles, decoded XCD-aware inside the kernel; launches of fewer
     // than kFlatMapBelow pairs (a.n_pairs = pairs of the launch) use a flat pairs x tiles grid instead
@@ -311,22 +326,40 @@ void launch_accumulate_c(int C, dim3 grid, hipStream_t st, const LevelArgs& a) {
 }
 
 template <int MODE>
-void launch_accumulate(int tt, int C, dim3 grid, hipStream_t st, const LevelArgs& a) {
+void launch_accumulate(int variant, int tt, int C, dim3 grid, hipStream_t st, const LevelArgs& a) {
   switch (tt) {
-    case ICA_TRANSLATION: launch_accumulate_c<ICA_TRANSLATION, MODE>(C, grid, st, a); break;
-    case ICA_EUCLIDEAN: launch_accumulate_c<ICA_EUCLIDEAN, MODE>(C, grid, st, a); break;
-    case ICA_SIMILARITY: launch_accumulate_c<ICA_SIMILARITY, MODE>(C, grid, st, a); break;
-    case ICA_AFFINITY: launch_accumulate_c<ICA_AFFINITY, MODE>(C, grid, st, a); break;
-    default: launch_accumulate_c<ICA_HOMOGRAPHY, MODE>(C, grid, st, a); break;
+    case ICA_TRANSLATION: launch_accumulate_c<ICA_TRANSLATION, MODE>(variant, C, grid, st, a); break;
+    case ICA_EUCLIDEAN: launch_accumulate_c<ICA_EUCLIDEAN, MODE>(variant, C, grid, st, a); break;
+    case ICA_SIMILARITY: launch_accumulate_c<ICA_SIMILARITY, MODE>(variant, C, grid, st, a); break;
+    case ICA_AFFINITY: launch_accumulate_c<ICA_AFFINITY, MODE>(variant, C, grid, st, a); break;
+    default: launch_accumulate_c<ICA_HOMOGRAPHY, MODE>(variant, C, grid, st, a); break;
   }
 }
 
-void launch_accumulate_mode(int mode, int tt, int C, dim3 grid, hipStream_t st, const LevelArgs& a) {
-  if (mode == kModeL2) launch_accumulate<kModeL2>(tt, C, grid, st, a);
-  else if (mode == kModeRobust) launch_accumulate<kModeRobust>(tt, C, grid, st, a);
-  else if (mode == kModeL2First && g_accum_variant == 2) launch_accumulate<kModeL2First>(tt, C, grid, st, a);
-  else if (mode == kModeL2First) launch_accumulate<kModeRobust>(tt, C, grid, st, a);  // v1: weights 1 at run time
-  else launch_accumulate<kModeHessian>(tt, C, grid, st, a);
+void launch_accumulate_mode(const ica_ctx* ctx, int mode, int tt, int C, dim3 grid, hipStream_t st, const LevelArgs& a) {
+  const int v = ctx->accum_variant;
+  if (mode == kModeL2) launch_accumulate<kModeL2>(v, tt, C, grid, st, a);
+  else if (mode == kModeRobust) launch_accumulate<kModeRobust>(v, tt, C, grid, st, a);
+  else if (mode == kModeL2First && v == 2 && (C == 1 || C == 3)) launch_accumulate<kModeL2First>(v, tt, C, grid, st, a);
+  else if (mode == kModeL2First) launch_accumulate<kModeRobust>(v, tt, C, grid, st, a);  // v1: weights 1 at run time
+  else launch_accumulate<kModeHessian>(v, tt, C, grid, st, a);
+}
+
+// Host side of the launch-sizing board: wait until the kernel of an earlier iteration has posted its
+// pair count (>= 0).  The usual wait is a few microseconds (the GPU is one iteration behind the host), so: a short
+// spin, then sched_yield, then 50 us sleeps -- a waiting context does not hold a core -- under a wall-clock limit.
+// Returns the count, or -1 on timeout.
+int wait_board(volatile int* slot, double timeout_s) {
+  int v = *slot;
+  for (int i = 0; v < 0 && i < 4000; ++i) v = *slot;
+  if (v >= 0) return v;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned n = 0; (v = *slot) < 0; ++n) {
+    if (n < 200) sched_yield();
+    else std::this_thread::sleep_for(std::chrono::microseconds(50));
+    if ((n & 15) == 15 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) break;
+  }
+  return v;
 }
 
 int launch_warp(ica_ctx* ctx, int batch, int C, int H, int W, int tt, const float* I2, const double* p,
@@ -335,14 +368,14 @@ int launch_warp(ica_ctx* ctx, int batch, int C, int H, int W, int tt, const floa
     const int nb = std::min(32768, batch - b0);
     const size_t off = (size_t)b0 * C * H * W;
     dim3 grid((W + 63) / 64, (H + kWaves - 1) / kWaves, nb);
-    if (C == 1)
-      hipLaunchKernelGGL(ica_warp_kernel<1>, grid, dim3(kBlock), 0, ctx->stream, I2 + off, I1 ? I1 + off : nullptr, H, W,
-                         tt, p + (size_t)b0 * 8, minmax + (size_t)b0 * 2, Iw ? Iw + off : nullptr,
-                         DI ? DI + off : nullptr);
-    else
-      hipLaunchKernelGGL(ica_warp_kernel<3>, grid, dim3(kBlock), 0, ctx->stream, I2 + off, I1 ? I1 + off : nullptr, H, W,
-                         tt, p + (size_t)b0 * 8, minmax + (size_t)b0 * 2, Iw ? Iw + off : nullptr,
-                         DI ? DI + off : nullptr);
+#define ICA_WARP_CASE(CC)                                                                                              \
+  case CC:                                                                                                             \
+    hipLaunchKernelGGL(ica_warp_kernel<CC>, grid, dim3(kBlock), 0, ctx->stream, I2 + off, I1 ? I1 + off : nullptr, H, W, \
+                       tt, p + (size_t)b0 * 8, minmax + (size_t)b0 * 2, Iw ? Iw + off : nullptr,                       \
+                       DI ? DI + off : nullptr);                                                                       \
+    break;
+    switch (C) { ICA_WARP_CASE(1) ICA_WARP_CASE(2) ICA_WARP_CASE(3) ICA_WARP_CASE(4) default: break; }
+#undef ICA_WARP_CASE
   }
   ICA_HIP(ctx, hipGetLastError());
   return ICA_OK;
@@ -354,7 +387,7 @@ int ensure_state(ica_ctx* ctx, const ica_problem* pr, const LevelGeom* g) {
   for (int s = 0; s < pr->nscales; ++s)
     for (int nb = 1; nb <= pr->batch; nb = (nb < pr->batch && nb * 2 > pr->batch) ? pr->batch : nb * 2) {
       LevelGeom t = g[s];
-      set_tiling(t, nb);
+      set_tiling(t, nb, ctx->max_tile_h);
       // the tiling is chosen for the polled count, which can only over-estimate the pairs of later launches
       max_slots_tiles = std::max(max_slots_tiles, (size_t)std::min<long>(pr->batch, 2L * nb) * t.tiles);
       if (nb == pr->batch) break;
@@ -429,8 +462,10 @@ int ica_create(int device, ica_ctx** out) {
   if (hipSetDevice(device) != hipSuccess) return ICA_ENODEVICE;
   auto* c = new ica_ctx();
   c->device = device;
-  if (const char* e = getenv("ICA_ACCUM")) g_accum_variant = (atoi(e) == 1) ? 1 : 2;
-  if (const char* e = getenv("ICA_SEPARATE_HESSIAN")) g_fold_hessian = atoi(e) == 0;
+  if (const char* e = getenv("ICA_ACCUM")) c->accum_variant = (atoi(e) == 1) ? 1 : 2;
+  if (const char* e = getenv("ICA_SEPARATE_HESSIAN")) c->fold_hessian = atoi(e) == 0;
+  if (const char* e = getenv("ICA_MAX_TILE_H")) c->max_tile_h = std::max(16, atoi(e));
+  if (const char* e = getenv("ICA_BOARD_TIMEOUT_MS")) c->board_timeout_s = std::max(1, atoi(e)) * 1e-3;
   *out = c;
   return ICA_OK;
 }
@@ -445,7 +480,18 @@ int ica_destroy(ica_ctx* ctx) {
 
 int ica_set_stream(ica_ctx* ctx, void* s) {
   if (!ctx) return ICA_EINVAL_ARG;
-  ctx->stream = reinterpret_cast<hipStream_t>(s);
+  hipStream_t ns = reinterpret_cast<hipStream_t>(s);
+  if (ns != ctx->stream) {
+    // A context owns ONE set of workspaces (partials, lists, pyramid levels, the host board): work queued on the
+    // stream it was bound to so far must finish before anything queued on the new stream touches them.  An event on
+    // the old stream, awaited by the new one, gives that order without stalling the host.  (A context is still
+    // single-threaded: one host thread at a time may call into it.)
+    ICA_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->handover) ICA_HIP(ctx, hipEventCreateWithFlags(&ctx->handover, hipEventDisableTiming));
+    ICA_HIP(ctx, hipEventRecord(ctx->handover, ctx->stream));
+    ICA_HIP(ctx, hipStreamWaitEvent(ns, ctx->handover, 0));
+    ctx->stream = ns;
+  }
   return ICA_OK;
 }
 
@@ -475,7 +521,7 @@ int ica_prepare(ica_ctx* ctx, const ica_problem* pr) {
   ICA_TRY(validate(pr));
   ICA_HIP(ctx, hipSetDevice(ctx->device));
   LevelGeom g[ICA_MAX_SCALES];
-  level_sizes(pr, g);
+  level_sizes(ctx, pr, g);
   return ensure_state(ctx, pr, g);
 }
 
@@ -486,7 +532,7 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
   ICA_TRY(validate(pr));
   ICA_HIP(ctx, hipSetDevice(ctx->device));
   LevelGeom g[ICA_MAX_SCALES];
-  level_sizes(pr, g);
+  level_sizes(ctx, pr, g);
   ICA_TRY(ensure_state(ctx, pr, g));
   hipStream_t st = ctx->stream;
   const int B = pr->batch, C = pr->channels, tt = pr->transform_type, n = nparams_of(tt);
@@ -559,10 +605,10 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
     // L2 (ref :96-103): the steepest-descent Hessian does not depend on p and is needed once per level.  Instead of a
     // separate pass over I1, iteration 0 runs the kernel variant that accumulates H next to b (weights identically 1)
     // and its solve stores inv(H) for the remaining iterations.  ICA_SEPARATE_HESSIAN=1 restores the separate pass.
-    const bool l2_fold_hessian = !robust && g_fold_hessian;
+    const bool l2_fold_hessian = !robust && ctx->fold_hessian;
     if (!robust && !l2_fold_hessian) {
       la.act_list = nullptr; la.act_count = nullptr; la.host_slot = nullptr;
-      launch_accumulate_mode(kModeHessian, tt, C, dim3(g[s].tiles, B), st, la);
+      launch_accumulate_mode(ctx, kModeHessian, tt, C, dim3(g[s].tiles, B), st, la);
       hipLaunchKernelGGL(ica_setup_solve_kernel, dim3(B), dim3(kSolveThreads), 0, st, la.partials, g[s].tiles, n,
                          ctx->hinv.as<double>());
     }
@@ -575,10 +621,11 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
         // The fused kernel of iteration it-1 posts "pairs that entered it-1" to host-visible memory when it starts;
         // that is an upper bound for iteration `it`.  Waiting for it keeps the host exactly one iteration ahead of
         // the GPU -- the queue never runs dry and no stream synchronisation is needed.
-        volatile int* slot = ctx->board + (size_t)s * max_iter + (it - 1);
-        int v = *slot, spins = 0;
-        while (v < 0 && spins < 200000000) { v = *slot; ++spins; }
-        if (v < 0) {  // should not happen: fall back to a synchronous read
+        int v = wait_board(ctx->board + (size_t)s * max_iter + (it - 1), ctx->board_timeout_s);
+        if (v < 0) {
+          // The count did not arrive in time.  Either the GPU is far behind (another process owns it) or a kernel of
+          // this solve has died: the synchronous read below tells the two apart -- a HIP error is reported to the
+          // caller with last_error set, a slow GPU just costs this one synchronisation.
           ICA_HIP(ctx, hipMemcpyAsync(ctx->pinned_count, counts + (size_t)cur * kListShards * kShardStride,
                                       kListShards * kShardStride * sizeof(int), hipMemcpyDeviceToHost, st));
           ICA_HIP(ctx, hipStreamSynchronize(st));
@@ -589,7 +636,7 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
         if (nb == 0) break;
       }
       la.host_slot = ctx->board_dev + (size_t)s * max_iter + it;
-      set_tiling(lg, nb);  // accumulate and solve of one iteration always agree on the tiling
+      set_tiling(lg, nb, ctx->max_tile_h);  // accumulate and solve of one iteration always agree on the tiling
       la.tiles_x = lg.tiles_x; la.tiles_y = lg.tiles_y; la.tile_h = lg.tile_h;
       la.act_list = lists + (size_t)cur * list_stride;
       la.act_count = counts + (size_t)cur * cnt_stride;
@@ -613,7 +660,7 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
       sa.invert_h = robust || first_l2;  // the solve inverts the H it receives ...
       sa.store_hinv = first_l2;          // ... and keeps the inverse for the later L2 iterations
       la.robust_type = first_l2 ? (int)ICA_QUADRATIC : pr->robust_type;
-      launch_accumulate_mode(robust ? kModeRobust : first_l2 ? kModeL2First : kModeL2, tt, C, dim3(lg.tiles, nb), st, la);
+      launch_accumulate_mode(ctx, robust ? kModeRobust : first_l2 ? kModeL2First : kModeL2, tt, C, dim3(lg.tiles, nb), st, la);
       if (ctx->profiling) {
         ICA_TRY(next_event(&e1));
         ICA_HIP(ctx, hipEventRecord(ctx->ev_pool[e1], st));
@@ -720,7 +767,7 @@ int ica_op_minmax_dev(ica_ctx* ctx, int batch, int channels, int height, int wid
 int ica_op_warp_dev(ica_ctx* ctx, int batch, int channels, int height, int width, int tt, const float* I2,
                     const double* p, const float* minmax, const float* I1, float* Iw_out, float* DI_out) {
   if (!ctx || !I2 || !p || batch <= 0 || height <= 0 || width <= 0) return ICA_EINVAL_ARG;
-  if (channels != 1 && channels != 3) return ICA_EINVAL_SHAPE;
+  if (channels < 1 || channels > ICA_MAX_CHANNELS) return ICA_EINVAL_SHAPE;
   if (nparams_of(tt) < 0) return ICA_EINVAL_TRANSFORM;
   if (DI_out && !I1) return ICA_EINVAL_ARG;
   ICA_HIP(ctx, hipSetDevice(ctx->device));
@@ -742,7 +789,7 @@ int ica_op_normal_equations_dev(ica_ctx* ctx, const ica_problem* pr, const float
   ica_problem one = *pr;
   one.nscales = 1;
   LevelGeom g[ICA_MAX_SCALES];
-  level_sizes(&one, g);
+  level_sizes(ctx, &one, g);
   ICA_TRY(ensure_state(ctx, &one, g));
   const int B = pr->batch, C = pr->channels, tt = pr->transform_type, n = nparams_of(tt);
   ICA_TRY(launch_minmax(ctx, B, (size_t)C * g[0].H * g[0].W, I2, ctx->minmax.as<float>()));
@@ -755,14 +802,14 @@ int ica_op_normal_equations_dev(ica_ctx* ctx, const ica_problem* pr, const float
   la.n_pairs = B;
   la.act_list = nullptr; la.act_count = nullptr;
   if (robust) {
-    launch_accumulate_mode(kModeRobust, tt, C, dim3(g[0].tiles, B), ctx->stream, la);
+    launch_accumulate_mode(ctx, kModeRobust, tt, C, dim3(g[0].tiles, B), ctx->stream, la);
     hipLaunchKernelGGL(ica_gather_normal_equations_kernel, dim3(B), dim3(kSolveThreads), 0, ctx->stream, la.partials, g[0].tiles, n,
                        B, 1, 1, (const double*)nullptr, H_out, b_out);
   } else {
-    launch_accumulate_mode(kModeHessian, tt, C, dim3(g[0].tiles, B), ctx->stream, la);
+    launch_accumulate_mode(ctx, kModeHessian, tt, C, dim3(g[0].tiles, B), ctx->stream, la);
     hipLaunchKernelGGL(ica_gather_normal_equations_kernel, dim3(B), dim3(kSolveThreads), 0, ctx->stream, la.partials, g[0].tiles, n,
                        B, 0, 1, (const double*)nullptr, H_out, b_out);
-    launch_accumulate_mode(kModeL2, tt, C, dim3(g[0].tiles, B), ctx->stream, la);
+    launch_accumulate_mode(ctx, kModeL2, tt, C, dim3(g[0].tiles, B), ctx->stream, la);
     hipLaunchKernelGGL(ica_gather_normal_equations_kernel, dim3(B), dim3(kSolveThreads), 0, ctx->stream, la.partials, g[0].tiles, n,
                        B, 1, 0, (const double*)nullptr, H_out, b_out);
   }
@@ -802,7 +849,7 @@ int ica_op_zoom_in_parameters_dev(ica_ctx* ctx, int batch, int tt, int w, int h,
 int ica_op_transform_image_dev(ica_ctx* ctx, int batch, int channels, int height, int width, const float* I,
                                const double* M, float* out) {
   if (!ctx || !I || !M || !out || batch <= 0 || height <= 0 || width <= 0) return ICA_EINVAL_ARG;
-  if (channels != 1 && channels != 3) return ICA_EINVAL_SHAPE;
+  if (channels < 1 || channels > ICA_MAX_CHANNELS) return ICA_EINVAL_SHAPE;
   ICA_HIP(ctx, hipSetDevice(ctx->device));
   ICA_HIP(ctx, ctx->mm_in.ensure((size_t)batch * 2 * sizeof(float)));
   ICA_TRY(launch_minmax(ctx, batch, (size_t)channels * height * width, I, ctx->mm_in.as<float>()));
@@ -810,12 +857,13 @@ int ica_op_transform_image_dev(ica_ctx* ctx, int batch, int channels, int height
     const int nb = std::min(32768, batch - b0);
     const size_t off = (size_t)b0 * channels * height * width;
     dim3 grid((width + 63) / 64, (height + kWaves - 1) / kWaves, nb);
-    if (channels == 1)
-      hipLaunchKernelGGL(ica_transform_image_kernel<1>, grid, dim3(kBlock), 0, ctx->stream, I + off, height, width,
-                         M + (size_t)b0 * 9, ctx->mm_in.as<float>() + (size_t)b0 * 2, out + off);
-    else
-      hipLaunchKernelGGL(ica_transform_image_kernel<3>, grid, dim3(kBlock), 0, ctx->stream, I + off, height, width,
-                         M + (size_t)b0 * 9, ctx->mm_in.as<float>() + (size_t)b0 * 2, out + off);
+#define ICA_TI_CASE(CC)                                                                                                  \
+  case CC:                                                                                                             \
+    hipLaunchKernelGGL(ica_transform_image_kernel<CC>, grid, dim3(kBlock), 0, ctx->stream, I + off, height, width,      \
+                       M + (size_t)b0 * 9, ctx->mm_in.as<float>() + (size_t)b0 * 2, out + off);                        \
+    break;
+    switch (channels) { ICA_TI_CASE(1) ICA_TI_CASE(2) ICA_TI_CASE(3) ICA_TI_CASE(4) default: break; }
+#undef ICA_TI_CASE
   }
   ICA_HIP(ctx, hipGetLastError());
   return ICA_OK;

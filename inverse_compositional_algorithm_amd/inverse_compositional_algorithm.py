@@ -62,8 +62,8 @@ def _run(I1, I2, p, transform_type, TOL, robust_type, lambda_, nanifoutside, del
         raise ValueError(_DIM_MSG)                                     # ref :55-56
     if TOL >= 0.01:
         raise ValueError(_TOL_MSG)                                     # ref :59-60
-    if I1.shape[2] not in (1, 3):
-        raise ValueError(_RGB_MSG)
+    if not 1 <= I1.shape[2] <= 4:
+        raise ValueError(_RGB_MSG)  # the library is built for 1..4 channels (differences)
     tt = TransformType(transform_type) if not isinstance(transform_type, TransformType) else transform_type
     rt = RobustErrorFunctionType(robust_type) if not isinstance(robust_type, RobustErrorFunctionType) else robust_type
     n = tt.nparams()
@@ -78,10 +78,11 @@ def _run(I1, I2, p, transform_type, TOL, robust_type, lambda_, nanifoutside, del
     if verbose:
         _print_trace(res.trace[0].cpu().numpy(), res.niter[0].cpu().numpy(), n, nscales,
                      rt != RobustErrorFunctionType.QUADRATIC, pyramidal, rt)
-    if isinstance(p, np.ndarray) and p.dtype == np.float64 and p.shape[0] >= n:
-        p[:n] = p_out      # the reference mutates the caller's array (transformation.py:54,68-70,...)
-        if not pyramidal:
-            p_out = p
+    if not pyramidal and isinstance(p, np.ndarray) and p.dtype == np.float64 and p.shape[0] >= n:
+        # the single-scale entry points mutate the caller's array and return it (transformation.py:54,68-70,...);
+        # the pyramidal driver works on its own copy, ps[0] = np.copy(p) (ref :323), and leaves the caller's p alone
+        p[:n] = p_out
+        p_out = p
     return p_out, error, _to_host(res.DI), _to_host(res.Iw)
 
 
@@ -93,8 +94,10 @@ def inverse_compositional_algorithm(I1, I2, p, transform_type, TOL, nanifoutside
 
 def robust_inverse_compositional_algorithm(I1, I2, p, transform_type, TOL, robust_type, lambda_, nanifoutside, delta,
                                            verbose):
-    """Robust inverse compositional algorithm.  reference: :135-261.  Like the reference, this entry point runs
-    the robust loop even for QUADRATIC (rho' = 1, Hessian re-inverted every iteration)."""
+    """Robust inverse compositional algorithm.  reference: :135-261.  For QUADRATIC the reference's robust loop
+    re-accumulates and re-inverts the same Hessian every iteration (rho' = 1); the library computes it once per level
+    (the L2 schedule) -- the iterates are the same.  Any channel count from 1 to 4 is accepted here (the reference's
+    robust entry point has no channel check, :168-177)."""
     return _run(I1, I2, p, transform_type, TOL, robust_type, lambda_, nanifoutside, delta, verbose, 1, 0.5,
                 need_rgb=False, pyramidal=False)
 

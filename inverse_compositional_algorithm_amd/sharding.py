@@ -52,6 +52,16 @@ def barrier(info: RankInfo, device=None) -> None:
         torch.cuda.synchronize(device)
 
 
+def count_ranks(info: RankInfo, device) -> int:
+    """How many ranks the process group really spans: every rank contributes a 1 to a SUM all-reduce.  bench.py
+    prints this as `n_gpus` and refuses to report when it differs from --gpus."""
+    if info.world <= 1:
+        return 1
+    one = torch.ones(1, dtype=torch.float64, device=device)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    return int(round(float(one[0])))
+
+
 def aggregate(info: RankInfo, seconds: float, units: float, pairs: float, device) -> tuple:
     """(max seconds over ranks, total units, total pairs)."""
     t = torch.tensor([seconds], dtype=torch.float64, device=device)

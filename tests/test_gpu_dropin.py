@@ -47,12 +47,26 @@ def test_robust_single_scale(capsys):
     assert len(lines) == want[4] and lines[0].endswith("lambda_=72.0")  # ref :253-257: lambda printed after its decay
 
 
+def test_robust_entry_point_takes_four_channels():
+    """No channel check in the reference's robust entry point (ref :168-177): RGBA-like input runs."""
+    from inverse_compositional_algorithm_amd.inverse_compositional_algorithm import robust_inverse_compositional_algorithm
+    from inverse_compositional_algorithm_amd import synthetic as syn
+    I1, I2, _ = syn.make_pair(321, 80, 104, 4, oc.TRANSLATION, robust_clutter=True)
+    I1, I2 = I1.astype(np.float64), I2.astype(np.float64)
+    out = robust_inverse_compositional_algorithm(I1, I2, np.zeros(2), T.TRANSLATION, 1e-3, R.LORENTZIAN, 0.0, True, 5, False)
+    want = oc.ica_single_scale(I1, I2, np.zeros(2), oc.TRANSLATION, 1e-3, oc.LORENTZIAN, 0.0, True, 5)
+    assert out[2].shape == (80, 104, 4)
+    assert np.linalg.norm(out[0] - want[0]) / np.linalg.norm(want[0]) <= 1e-4
+
+
 def test_pyramidal(capsys):
     from inverse_compositional_algorithm_amd.inverse_compositional_algorithm import pyramidal_inverse_compositional_algorithm
     I1, I2 = _pair(oc.HOMOGRAPHY, seed=99)
-    out = pyramidal_inverse_compositional_algorithm(I1=I1, I2=I2, p=np.zeros(8), transform_type=T.HOMOGRAPHY, nscales=2,
+    p0 = np.zeros(8)
+    out = pyramidal_inverse_compositional_algorithm(I1=I1, I2=I2, p=p0, transform_type=T.HOMOGRAPHY, nscales=2,
                                                     nu=0.5, TOL=1e-3, robust_type=R.QUADRATIC, lambda_=0, nanifoutside=True,
                                                     delta=5, verbose=True)
+    assert out[0] is not p0 and not p0.any()  # the pyramidal driver works on ps[0] = np.copy(p) (ref :323)
     want = oc.ica_pyramidal(I1, I2, np.zeros(8), oc.HOMOGRAPHY, 2, 0.5, 1e-3, oc.QUADRATIC, 0.0, True, 5, need_rgb=True)
     _check(*out, want, oc.HOMOGRAPHY)
     text = capsys.readouterr().out
@@ -96,7 +110,7 @@ def test_host_pointer_entry_point_matches_device_entry_point():
     bad = eng.problem(B, H, W, Cn, t, 0, tol=0.01)
     assert eng.lib.ica_solve_batch(eng.ctx, C.byref(bad), ptr(i1), ptr(i2), ptr(p), ptr(err), ptr(nit), None, None, None,
                                    None) == -3
-    bad = eng.problem(B, H, W, 2, t, 0)
+    bad = eng.problem(B, H, W, 5, t, 0)  # more than ICA_MAX_CHANNELS
     assert eng.lib.ica_solve_batch(eng.ctx, C.byref(bad), ptr(i1), ptr(i2), ptr(p), ptr(err), ptr(nit), None, None, None,
                                    None) == -1
 

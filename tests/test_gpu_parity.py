@@ -191,6 +191,18 @@ def test_pyramid_down_other_factors(eng, nu):
         np.testing.assert_allclose(got[i], want, atol=2e-4)
 
 
+@pytest.mark.parametrize("nu", [0.1, 0.07])
+def test_pyramid_down_very_small_factor(eng, nu):
+    """The reference accepts any nu; factors below ~0.12 exceed what the tiled passes are sized for and run the generic
+    banded pass (vertical: a 16-output window wider than 160 input rows)."""
+    rng = np.random.default_rng(int(nu * 1000))
+    imgs = [np.round(rng.uniform(0, 255, (300, 260, 3)))]
+    got = to_np(eng.pyramid_down(to_dev(eng, *imgs), nu))
+    want = oc.rescale_restated(imgs[0], nu)
+    assert got[0].shape == want.shape
+    np.testing.assert_allclose(got[0], want, atol=2e-4)
+
+
 def test_zoom_in_parameters(eng):
     for t in TYPES:
         p = np.zeros((3, 8))
@@ -408,14 +420,92 @@ def test_seeded_random_configurations_match_oracle(eng, case):
     n = oc.nparams(t)
     I1, I2, _ = syn.make_pair(5000 + k, H_, W_, C, t, robust_clutter=(r != 0))
     prob = eng.problem(1, H_, W_, C, t, r, nscales=ns, nu=nu, delta=delta, lambda_=lam)
-    res = eng.solve(to_dev(eng, I1), to_dev(eng, I2), prob)
+    res = eng.solve(to_dev(eng, I1), to_dev(eng, I2), prob, want_trace=True)
+    traces = []
     want, e_w, _, _, nit = oc.ica_pyramidal(I1.astype(np.float64), I2.astype(np.float64), np.zeros(n), t, ns, nu, 1e-3, r, lam,
-                                           True, delta)
+                                           True, delta, traces=traces)
     got_nit = list(res.niter[0].cpu().numpy())
     p = res.p[0, :n].cpu().numpy()
-    if max(nit) >= 30:
-        # a scale that exhausts its iterations is a non-converged trajectory: fp32 vs float64 may part ways on it
-        assert got_nit[-1] == nit[-1] or max(got_nit) >= 30
+    if max(nit) < 30:
+        assert got_nit == nit, (case, got_nit, nit)
+        assert np.linalg.norm(p - want) / max(np.linalg.norm(want), 1e-3) <= 1e-4, (case, p, want)
         return
-    assert got_nit == nit, (case, got_nit, nit)
-    assert np.linalg.norm(p - want) / max(np.linalg.norm(want), 1e-3) <= 1e-4, (case, p, want)
+    # A scale that exhausts its 30 iterations is a non-converged trajectory, the kind most sensitive to fp32-vs-float64
+    # drift.  Every scale before it (coarse to fine) must still agree in iteration count and iterate by iterate; on the
+    # exhausting scale itself both sides must run all 30 iterations and the first iterates must agree; the scales
+    # after it started from slightly different parameters, so only the final transforms are compared, by how far
+    # they move the image corners.
+    tr = res.trace[0].cpu().numpy()              # [scale][iteration][|dp|, p0..p7, lambda]
+    sizes = [(W_, H_)]
+    for _ in range(1, ns):
+        sizes.append(oc.zoom_size(sizes[-1][0], sizes[-1][1], nu))
+    first_cap = next(s for s, _ in traces if nit[s] >= 30)   # traces run coarse to fine
+    for s, its in traces:
+        if s < first_cap:
+            break
+        assert got_nit[s] == nit[s], (case, s, got_nit, nit)
+        upto = len(its) if s > first_cap else 8
+        for it in range(min(upto, len(its))):
+            d = corners_disp(tr[s, it, 1:1 + n], its[it]["p"], t, sizes[s][1], sizes[s][0])
+            assert d <= 5e-3, (case, s, it, d)
+    assert corners_disp(p, want, t, H_, W_) <= 0.25, (case, p, want)
+
+
+def test_one_engine_under_two_streams_matches_serial(eng):
+    """ica_set_stream orders a newly bound stream behind the work queued on the previous one (a context owns one set of
+    workspaces): two solves issued back to back on ONE engine under two torch streams give exactly the serial results."""
+    t, n, B = oc.AFFINITY, 6, 24
+    sets = []
+    for base in (3100, 3200):
+        prs = [syn.make_pair(base + i, 96, 128, 1, t) for i in range(B)]
+        sets.append((to_dev(eng, *[a for a, _, _ in prs]), to_dev(eng, *[b for _, b, _ in prs])))
+    prob = eng.problem(B, 96, 128, 1, t, 0, nscales=2, delta=5)
+    serial = [eng.solve(a, b, prob) for a, b in sets]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=eng.device) for _ in sets]
+    out = []
+    for (a, b), st in zip(sets, streams):
+        with torch.cuda.stream(st):
+            out.append(eng.solve(a, b, prob))
+    torch.cuda.synchronize()
+    for r, w in zip(out, serial):
+        assert torch.equal(r.p, w.p) and torch.equal(r.niter, w.niter) and torch.equal(r.error, w.error)
+
+
+@pytest.mark.parametrize("C", [2, 4])
+def test_two_and_four_channel_images(eng, C):
+    """The reference's robust entry point takes any channel count (ref :168-177); 2 and 4 channels run the
+    direct-gather kernel.  One robust single-scale solve and one L2 pyramid against the oracle."""
+    t, n = oc.SIMILARITY, 4
+    I1, I2, _ = syn.make_pair(4100 + C, 90, 120, C, t, robust_clutter=True)
+    for robust, ns in ((oc.LORENTZIAN, 1), (oc.QUADRATIC, 2)):
+        prob = eng.problem(1, 90, 120, C, t, robust, nscales=ns, delta=5)
+        res = eng.solve(to_dev(eng, I1), to_dev(eng, I2), prob, want_images=True)
+        want, _, DI, Iw, nit = oc.ica_pyramidal(I1.astype(np.float64), I2.astype(np.float64), np.zeros(n), t, ns, 0.5, 1e-3,
+                                               robust, 0.0, True, 5)
+        assert list(res.niter[0].cpu().numpy()) == nit
+        p = res.p[0, :n].cpu().numpy()
+        assert np.linalg.norm(p - want) / np.linalg.norm(want) <= P_REL_TOL
+        assert np.array_equal(np.isnan(to_np(res.Iw)[0]), np.isnan(Iw))
+
+
+def _skimage_cases():
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "skimage_warp.npz"))
+    kind = {"translation": oc.TRANSLATION, "integer_translation": oc.TRANSLATION, "euclidean": oc.EUCLIDEAN,
+            "similarity": oc.SIMILARITY, "affinity": oc.AFFINITY, "affinity_round_numbers": oc.AFFINITY,
+            "homography": oc.HOMOGRAPHY, "homography_gray_large_shift": oc.HOMOGRAPHY}
+    return [(n, kind[n], z[n + "__img"].astype(np.float64), z[n + "__M"], z[n + "__out"]) for n in sorted(kind)]
+
+
+@pytest.mark.parametrize("case", _skimage_cases(), ids=lambda c: c[0])
+def test_warp_against_scikit_image_outputs(eng, case):
+    """The HIP warp against genuine scikit-image 0.18.3 outputs (tests/golden/skimage_warp.npz; reference call site
+    bicubic_interpolation.py:199): NaN mask identical -- including the maps whose sampling positions are exact
+    integers, where the in/out decision of a border pixel hangs on floor() -- and values within fp32 rounding."""
+    name, t, img, M, want = case
+    p = oc.matrix2params(M, t)
+    np.testing.assert_allclose(oc.params2matrix(p, t), M, atol=1e-14)
+    Iw = to_np(eng.warp(to_dev(eng, img), torch.from_numpy(p[None]), t))[0]
+    assert np.array_equal(np.isnan(Iw), np.isnan(want)), name
+    np.testing.assert_allclose(np.nan_to_num(Iw), np.nan_to_num(want), atol=2e-3)

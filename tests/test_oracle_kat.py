@@ -139,3 +139,29 @@ def test_kat_l2_rotation_single_scale():
     oc.ica_single_scale(_transform_image(I2, "rubber_whale_rt"), I2, np.zeros(3), oc.EUCLIDEAN, 1e-3, trace=tr,
                         need_rgb=True)
     _compare(ref, tr, 1e-9)
+
+
+# ---- the warp restatement against GENUINE scikit-image output --------------------------------------------------
+def _skimage_warp_cases():
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "skimage_warp.npz"))
+    names = sorted({k.split("__")[0] for k in z.files if "__" in k})
+    return z, names
+
+
+def test_keys_warp_reproduces_scikit_image():
+    """oracle.keys_warp vs skimage.transform.warp(order=3, mode="constant", cval=nan, preserve_range=True) as called at
+    reference bicubic_interpolation.py:199.  The fixture holds scikit-image 0.18.3's own outputs
+    (tests/golden/make_skimage_warp_fixtures.py, run with /opt/conda/bin/python3.9) for a translation, a Euclidean map,
+    a similarity, an affinity, two homographies and two maps whose sampling positions fall exactly on integers:
+    values bit-identical, NaN masks identical.  This pins the warp for the transform classes that have no stored
+    trace in the reference's notebooks (affinity, homography)."""
+    z, names = _skimage_warp_cases()
+    assert str(z["skimage_version"]).startswith("0.18")
+    assert {"affinity", "homography", "translation", "integer_translation"} <= set(names)
+    for n in names:
+        img, M, want = z[n + "__img"].astype(np.float64), z[n + "__M"], z[n + "__out"]
+        got = oc.keys_warp(img, M)
+        assert np.array_equal(np.isnan(got), np.isnan(want)), n
+        assert np.isnan(want).any() and not np.isnan(want).all(), n
+        np.testing.assert_array_equal(np.nan_to_num(got), np.nan_to_num(want), err_msg=n)

@@ -46,3 +46,43 @@ def test_single_rank_is_a_no_op():
     info = sharding.RankInfo(0, 1, 0)
     assert sharding.aggregate(info, 1.5, 10.0, 2.0, torch.device("cpu")) == (1.5, 10.0, 2.0)
     assert sharding.shard_range(7, 0, 1) == (0, 7)
+
+
+# ---- bench.py's own launch path (CPU: the stub engine + gloo stand in for the GPUs + RCCL) -------------------
+def _bench(args, env_extra, timeout=240):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r.returncode, (json.loads(lines[-1]) if lines else None), r.stderr
+
+
+def test_bench_gpus_2_spawns_two_ranks_and_counts_them():
+    """`python bench.py --gpus 2` without torchrun starts its two ranks itself; the ranks count themselves with an
+    all-reduce and that count is what the JSON line reports."""
+    rc, out, err = _bench(["--gpus", "2", "--steps", "3", "--warmup", "0"], {"BENCH_STUB": "1"})
+    assert rc == 0, err[-2000:]
+    assert out["n_gpus"] == 2 and out["stub"] is True
+    assert out["units"] == 100.0 * 3 * (1 + 2) and out["pairs"] == 2 * 8.0 * 3  # SUM over both ranks
+
+
+def test_bench_refuses_a_rank_count_that_differs_from_gpus():
+    """Started as ONE rank (as a launcher that ignored --gpus would) bench.py exits non-zero instead of printing a
+    1-rank number under an N-GPU label."""
+    rc, out, err = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0"],
+                          {"BENCH_STUB": "1", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+    assert rc != 0 and out is None
+    assert "refusing" in err
+
+
+def test_bench_without_a_gpu_fails_loudly():
+    """No GPU, no stub: the product path must fail, not fall back to a CPU computation."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    rc, out, err = _bench(["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-per-config"], {})
+    assert rc != 0 and out is None
