@@ -17,7 +17,7 @@
 
 #include "../../include/ica_hip.h"
 #include "ica_kernels.hpp"
-#include "ica_accumulate2.hpp"
+#include "ica_iterate_launch.hpp"
 #include "ica_pyramid.hpp"
 
 using namespace ica;
@@ -124,6 +124,7 @@ int validate(const ica_problem* pr) {
   if (!pr) return ICA_EINVAL_ARG;
   if (pr->channels < 1 || pr->channels > ICA_MAX_CHANNELS) return ICA_EINVAL_SHAPE;
   if (pr->batch <= 0 || pr->height <= 0 || pr->width <= 0) return ICA_EINVAL_ARG;
+  if (pr->height >= (1 << 20) || pr->width >= (1 << 20)) return ICA_EINVAL_ARG;  // 20-bit fields in the chunk plan
   if (!(pr->tol < 0.01)) return ICA_EINVAL_TOL;  // ref :59-60
   if (nparams_of(pr->transform_type) < 0) return ICA_EINVAL_TRANSFORM;
   if (pr->robust_type < ICA_QUADRATIC || pr->robust_type > ICA_CHARBONNIER) return ICA_EINVAL_ROBUST;
@@ -137,7 +138,7 @@ int validate(const ica_problem* pr) {
 // use short tiles and spread those pairs over the whole chip instead of running 16 long workgroups per pair.
 void set_tiling(LevelGeom& g, int pairs, int max_tile_h) {
   g.tiles_x = (g.W + kTileW - 1) / kTileW;
-  int th = std::max(16, std::min(512, max_tile_h));   // (at most 64 chunks of 16 rows per tile: one lane plans one chunk)
+  int th = std::max(16, std::min(512, max_tile_h));   // (at most 32 chunks of 16 rows per tile: the chunk plans of a tile live in one register)
   while (th > 16) {
     const long blocks = (long)pairs * g.tiles_x * ((g.H + th - 1) / th);
     if (blocks >= 2048 && th <= std::max(16, g.H)) break;
@@ -315,13 +316,10 @@ void launch_accumulate_c(int variant, int C, dim3 grid, hipStream_t st, const Le
   } else {
     // 1-D grid: (pairs rounded up to a multiple of 8) x tiles, decoded XCD-aware inside the kernel; launches of fewer
     // than kFlatMapBelow pairs (a.n_pairs = pairs of the launch) use a flat pairs x tiles grid instead
-    const dim3 g1((unsigned)((int)grid.y < kFlatMapBelow ? grid.y * grid.x : ((grid.y + 7) / 8) * 8 * grid.x));
+    const unsigned blocks = (unsigned)((int)grid.y < kFlatMapBelow ? grid.y * grid.x : ((grid.y + 7) / 8) * 8 * grid.x);
     LevelArgs al = a;
     al.n_pairs = (int)grid.y;  // the kernel picks the same map from it
-    if (C == 1)
-      hipLaunchKernelGGL((ica_accumulate2_kernel<TT, MODE, 1>), g1, dim3(kBlock), 0, st, al);
-    else
-      hipLaunchKernelGGL((ica_accumulate2_kernel<TT, MODE, 3>), g1, dim3(kBlock), 0, st, al);
+    launch_iterate(TT, MODE, C, a.robust_type, blocks, st, al);
   }
 }
 

@@ -1,0 +1,822 @@
+// Fused per-iteration pass, LDS-staged + double-buffered (the production kernel).
+//
+// One workgroup (4 waves) owns a 64-column x tile_h-row tile of one image pair and walks it in chunks of
+// CH rows.  For every chunk:
+//   1. The footprint of the chunk under the current warp is the convex quadrilateral of its 4 mapped
+//      corners; its bounding box (+ bicubic halo) of I2 and the chunk (+1-px halo) of I1 are moved
+//      HBM/L2 -> LDS by LDS-DMA (buffer_load ... lds, 16 B per lane, no VGPRs).  The copy for chunk k+1 is issued
+//      right after the barrier that publishes chunk k, so it runs underneath chunk k's arithmetic
+//      (two LDS buffers, one barrier per chunk).  A footprint that does not fit the buffer falls back to
+//      direct cached gathers for that chunk -- same arithmetic, same results.
+//   2. Each lane owns one image column; each wave walks RW consecutive rows.  All 16 bicubic taps and the
+//      5-point gradient stencil come from LDS with compile-time offsets; nothing but the two images is ever
+//      read from memory (the reference materialises 192 B/pixel of gradient/Jacobian/steepest-descent tensors).
+//   3. "Moment" accumulation.  Every Jacobian entry is a monomial c*x^a*y^b (derivatives.py:33-68), so
+//        b_k  = sum_pix (Jx_k Gx + Jy_k Gy),                 Gx = rho' * sum_c Ix_c DI_c, Gy likewise
+//        H_km = sum_pix (Jx_k Jx_m Sxx + (Jx_k Jy_m + Jy_k Jx_m) Sxy + Jy_k Jy_m Syy),  Sxx = rho' sum_c Ix_c^2 ...
+//      x^a is constant per lane and factors out of the row loop: per pixel only the y-moments
+//      sum_y y^b G* and sum_y y^b S** are accumulated (4 FMAs for affine L2 instead of 6 products + 6 FMAs;
+//      12 + 5 instead of (36 + 8 + 8) * C for robust homography, independent of C).  The x powers are applied
+//      once per tile, in fp64, when the 64 lanes' moments are folded into the <= 44 sums.
+//   fp32 per pixel, promoted to fp64 at the end of the tile; fixed summation order throughout (deterministic).
+//
+// Two instruction streams per chunk.  The kernel is bound by VALU issue and LDS reads, not by HBM, and on gfx950 the
+// issue cost of a vector instruction depends on its FORM (measured, tools/ubench/issue_cost.hip, 6 waves per SIMD,
+// relative to a VOP2 on registers = 1): VOP3 fma 1.35, anything with an SGPR operand 1.5-2.4, packed fp32 2.3 (for
+// two results), 3-operand integer forms 2.4, DPP / mad24 2.9, v_cndmask on vcc far more.  So:
+//   * INTERIOR chunks -- no pixel in the NaN frame or on the gradient border, every bicubic footprint inside I2,
+//     decided once per chunk from the mapped corners (the large majority of a level-0 image) -- run `band_fast`:
+//     no masks, no validity tests, no selects; 4 rows unrolled; every wave-uniform operand (y powers, warp
+//     coefficients, clip range, lambda^2) is kept in a VGPR so the multiply-adds are VOP2 v_fmac on registers; the
+//     robust function is a template argument (no branches in the loop); v_fract + v_cvt_flr instead of
+//     floor/subtract/convert; the Keys weights in their factored form (10 operations per axis instead of 14).
+//   * BORDER chunks run `band_careful`, which keeps every test of the reference's pixel masks, and re-evaluates a
+//     sampling position in float64 when its fp32 value is within 2^-16 of an integer: there floor() decides whether a
+//     border pixel's 4x4 footprint counts as inside the image (bicubic_interpolation.py:199, cval=nan), and fp32 and
+//     the reference's float64 could otherwise part ways.
+#pragma once
+#include <type_traits>
+
+#ifndef ICA_ITER_WAVES
+#define ICA_ITER_WAVES 6
+#endif
+#ifndef ICA_ROW_FENCE
+#define ICA_ROW_FENCE 1
+#endif
+#ifndef ICA_NBUF
+#define ICA_NBUF 2
+#endif
+#ifndef ICA_CH
+#define ICA_CH 16
+#endif
+#ifndef ICA_R2
+#define ICA_R2 (ICA_CH + 9)
+#endif
+
+#include "ica_common.hpp"
+
+namespace ica {
+
+struct Mono { signed char c, a, b; };  // c * x^a * y^b; c == 0: structurally zero
+
+// Jacobian rows dW/dp (derivatives.py:33-68) as monomials; jac_x(tt, k) = dx'/dp_k, jac_y(tt, k) = dy'/dp_k
+__host__ __device__ constexpr Mono jac_x(int tt, int k) {
+  constexpr Mono Z{0, 0, 0}, ONE{1, 0, 0}, X{1, 1, 0}, Y{1, 0, 1}, NY{-1, 0, 1}, NXX{-1, 2, 0}, NXY{-1, 1, 1};
+  switch (tt) {
+    case ICA_TRANSLATION: return k == 0 ? ONE : Z;
+    case ICA_EUCLIDEAN: return k == 0 ? ONE : k == 2 ? NY : Z;
+    case ICA_SIMILARITY: return k == 0 ? ONE : k == 2 ? X : k == 3 ? NY : Z;
+    case ICA_AFFINITY: return k == 0 ? ONE : k == 2 ? X : k == 3 ? Y : Z;
+    case ICA_HOMOGRAPHY: return k == 0 ? X : k == 1 ? Y : k == 2 ? ONE : k == 6 ? NXX : k == 7 ? NXY : Z;
+    default: return Z;
+  }
+}
+__host__ __device__ constexpr Mono jac_y(int tt, int k) {
+  constexpr Mono Z{0, 0, 0}, ONE{1, 0, 0}, X{1, 1, 0}, Y{1, 0, 1}, NXY{-1, 1, 1}, NYY{-1, 0, 2};
+  switch (tt) {
+    case ICA_TRANSLATION: return k == 1 ? ONE : Z;
+    case ICA_EUCLIDEAN: return k == 1 ? ONE : k == 2 ? X : Z;
+    case ICA_SIMILARITY: return k == 1 ? ONE : k == 2 ? Y : k == 3 ? X : Z;
+    case ICA_AFFINITY: return k == 1 ? ONE : k == 4 ? X : k == 5 ? Y : Z;
+    case ICA_HOMOGRAPHY: return k == 3 ? X : k == 4 ? Y : k == 5 ? ONE : k == 6 ? NXY : k == 7 ? NYY : Z;
+    default: return Z;
+  }
+}
+
+// highest y power among the Jx (mbx) / Jy (mby) entries of each transform
+template <int TT> struct MomShape;
+template <> struct MomShape<ICA_TRANSLATION> { static constexpr int mbx = 0, mby = 0; };
+template <> struct MomShape<ICA_EUCLIDEAN> { static constexpr int mbx = 1, mby = 0; };
+template <> struct MomShape<ICA_SIMILARITY> { static constexpr int mbx = 1, mby = 1; };
+template <> struct MomShape<ICA_AFFINITY> { static constexpr int mbx = 1, mby = 1; };
+template <> struct MomShape<ICA_HOMOGRAPHY> { static constexpr int mbx = 1, mby = 2; };
+
+template <int TT> struct MomLayout {
+  static constexpr int mbx = MomShape<TT>::mbx, mby = MomShape<TT>::mby;
+  static constexpr int ngx = mbx + 1, ngy = mby + 1, nxx = 2 * mbx + 1, nxy = mbx + mby + 1, nyy = 2 * mby + 1;
+  static constexpr int ogx = 0, ogy = ngx, oxx = ngx + ngy, oxy = oxx + nxx, oyy = oxy + nxy;
+  static constexpr int nmom = oyy + nyy;  // <= 17
+  static constexpr int maxpow = 2 * mby > 2 * mbx ? 2 * mby : 2 * mbx;  // highest y power any moment needs
+};
+
+template <int C> struct TileCfg {
+  static constexpr int ch = ICA_CH;                    // image rows per chunk: 4 waves x ch/4 rows
+  static constexpr int rw = ch / kWaves;
+  static constexpr int p2 = 80, r2 = ICA_R2;           // I2 footprint buffer: pitch (floats) x rows
+  static constexpr int p1 = 72, r1 = ch + 2;           // I1 buffer: columns x_t0-4 .. x_t0+67, rows yc0-1 .. yc0+ch
+  // C == 1: two buffers (26 KB -> 6 workgroups per CU): chunk k is computed while k+1 is in flight.
+  // C == 3: one buffer (40.5 KB), copy and arithmetic of one workgroup alternate, 3 workgroups overlap.
+  static constexpr int nbuf = (C == 1) ? ICA_NBUF : 1;
+  static constexpr int buf_floats = C * (p2 * r2 + p1 * r1);
+};
+
+// 4 bytes per lane, global -> LDS at (wave-uniform) lds_base + 4*lane: rows that are not 16-byte aligned
+__device__ __forceinline__ void glds4(const float* gsrc, float* lds_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_base, 4, 0, 0);
+}
+
+// A wave-uniform value the compiler would keep in an SGPR (a VALU operand read from an SGPR costs 1.5-2.4x the
+// issue time of the same instruction on a VGPR, see the header): pin it to a VGPR.
+__device__ __forceinline__ float in_vgpr(float v) {
+  asm("" : "+v"(v));
+  return v;
+}
+// the same, but placed where it is written (a volatile asm is neither hoisted out of a loop nor merged)
+__device__ __forceinline__ float pin_vgpr(float v) {
+  float r;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(v));
+  return r;
+}
+__device__ __forceinline__ int in_vgpr(int v) {
+  asm("" : "+v"(v));
+  return v;
+}
+// floor(x) as an integer in one instruction (v_floor_f32 + v_cvt_i32_f32 otherwise)
+__device__ __forceinline__ int floor_to_int(float x) {
+  int r;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
+template <bool PROJ>
+__device__ __forceinline__ void displacement_col(const float* A, float cx, float cy, float gx, float xf, float yf,
+                                                 float& dx, float& dy) {
+  // displacement<>() with the per-column terms (cx = a0 x + a2, cy = a3 x + a5, gx = a6 x) hoisted
+  float nx = fmaf(A[1], yf, cx);
+  float ny = fmaf(A[4], yf, cy);
+  if constexpr (PROJ) {
+    const float g = fmaf(A[7], yf, gx);
+    const float r = rcp_nr(1.0f + g);
+    nx = (nx - xf * g) * r;
+    ny = (ny - yf * g) * r;
+  }
+  dx = nx;
+  dy = ny;
+}
+
+// rho'(t^2; lambda) with the error function known at compile time (no branches in the pixel loop).  The hardware
+// reciprocal / reciprocal square root are good to 1 ulp, which is all a per-pixel WEIGHT needs (the same weight
+// multiplies the pixel's contribution to H and to b); the sampling POSITION keeps its Newton step (rcp_nr).
+template <int RT>
+__device__ __forceinline__ float rho_prime_t(float t2, float lam2) {
+  if constexpr (RT == ICA_TRUNCATED_QUADRATIC) return t2 < lam2 ? 1.0f : 0.0f;
+  else if constexpr (RT == ICA_GERMAN_MCCLURE) {
+    const float s = lam2 + t2;
+    return lam2 * __builtin_amdgcn_rcpf(s * s);
+  } else if constexpr (RT == ICA_LORENTZIAN) return __builtin_amdgcn_rcpf(lam2 + t2);
+  else if constexpr (RT == ICA_CHARBONNIER) return __builtin_amdgcn_rsqf(t2 + lam2);
+  else return 1.0f;
+}
+
+template <int TT, int MODE, int C, int RT>
+// (second launch bound = waves per SIMD the register allocator must leave room for: what the LDS footprint allows)
+__global__ __launch_bounds__(kBlock, (C == 1 ? ICA_ITER_WAVES : 1)) void ica_iterate_kernel(LevelArgs a) {
+  constexpr int N = NP<TT>::n;
+  constexpr int NT = N * (N + 1) / 2;
+  constexpr bool kB = (MODE != kModeHessian);
+  constexpr bool kH = (MODE != kModeL2);
+  constexpr bool kProj = (TT == ICA_HOMOGRAPHY);
+  constexpr bool kRobust = (MODE == kModeRobust);
+  using ML = MomLayout<TT>;
+  using TC = TileCfg<C>;
+  constexpr int CH = TC::ch, RW = TC::rw, P2 = TC::p2, R2 = TC::r2, P1 = TC::p1, R1 = TC::r1, NBUF = TC::nbuf;
+  constexpr int NMOM = ML::nmom;
+  constexpr unsigned kPitchBits = P2 == 80 ? 0x43a00000u : P2 == 96 ? 0x43c00000u : 0u;  // (float)(P2 * 4)
+  static_assert(kPitchBits != 0, "add the bit pattern of (float)(P2 * 4)");
+
+  // The ring buffers; the end-of-tile fold reuses the same LDS.  The fold works on the moments in two halves when a
+  // single pass would need more LDS than the ring (robust homography), so that it never costs an occupancy step.
+  constexpr int kRingFloats = NBUF * TC::buf_floats;
+  constexpr int kFoldAll = 2 * (NMOM + N + NT) * 64;
+  constexpr int kLdsFloats = kRingFloats > 2 * (NMOM + (N + NT + 1) / 2) * 64 ? kRingFloats : 2 * (NMOM + (N + NT + 1) / 2) * 64;
+  constexpr bool kFoldSplit = kFoldAll > kLdsFloats;
+  __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
+
+  // XCD-aware block -> (pair, tile) map.  Workgroups are dealt round-robin to the 8 XCDs (blocks b and b+8 share
+  // an L2), so consecutive block ids take different PAIRS and the blocks that share an XCD walk through the tiles
+  // of the same pair: tile halos and the rows two chunks share are then served by that XCD's L2.  (Placement is a
+  // speed matter only; nothing depends on it for correctness.)
+  // With few pairs in the launch that map leaves XCDs idle or unevenly loaded (a single straggler pair would run on
+  // one eighth of the chip): then the tiles of a pair are simply dealt to consecutive workgroups, i.e. round-robin
+  // over all XCDs (those launches are latency-bound, not traffic-bound).
+  const int ntiles = a.tiles_x * a.tiles_y;
+  const bool flat = a.n_pairs < kFlatMapBelow;
+  const int slot = flat ? (int)blockIdx.x : (int)(blockIdx.x >> 3), xcd = blockIdx.x & 7;
+  const int pair_slot = flat ? slot / ntiles : (slot / ntiles) * 8 + xcd;
+  const int tile_id = slot - (slot / ntiles) * ntiles;
+  int pair = pair_slot;
+  if (a.act_list) {
+    // tell the host how many pairs entered this iteration (it sizes the next launch from it, without a sync)
+    if (a.host_slot && blockIdx.x == 0 && threadIdx.x == 0)
+      __hip_atomic_store(a.host_slot, list_total(a.act_count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (pair_slot >= list_total(a.act_count)) return;
+    pair = list_entry(a.act_list, a.act_count, a.list_cap, pair_slot);
+  } else if (pair_slot >= a.n_pairs) {
+    return;
+  }
+  const int tx = tile_id % a.tiles_x, ty = tile_id / a.tiles_x;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int H = a.H, W = a.W;
+  const size_t plane = (size_t)H * W;
+  const float* I1 = a.I1 + (size_t)pair * C * plane;
+  const float* I2 = a.I2 + (size_t)pair * C * plane;
+
+  float A[8];
+  float lo = 0.f, hi = 0.f, lam2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) A[i] = 0.f;
+  bool ident = true;  // all |p_i| < 1e-10: the reference warps with the identity (bicubic_interpolation.py:173-175)
+  if constexpr (kB) {
+    double ad[8];
+    params_to_displacement(a.p + (size_t)pair * 8, TT, ad);
+#pragma unroll
+    for (int i = 0; i < N; ++i) ident = ident & (fabs(a.p[(size_t)pair * 8 + i]) < 1e-10);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) A[i] = (float)ad[i];
+    lo = a.minmax[pair * 2];
+    hi = a.minmax[pair * 2 + 1];
+    if constexpr (kRobust) {
+      const float l = (float)a.lambda_it[pair];
+      lam2 = l * l;
+    }
+  }
+
+  const int x_t0 = tx * kTileW;
+  const int x = x_t0 + lane;
+  const float xf = (float)x;
+  const int y_begin = ty * a.tile_h;
+  const int y_end = min(H, y_begin + a.tile_h);
+  const int nchunks = (y_end - y_begin + CH - 1) / CH;  // <= 32: one lane plans one chunk (tile_h <= 32 * CH, host-checked)
+  const bool frame_on = a.nanif && a.delta > 0;
+  const bool col_ok = (x < W) & !(frame_on & ((x < a.delta) | (x >= W - a.delta)));
+  const float cmx = ((x >= 1) & (x <= W - 2)) ? 1.0f : 0.0f;  // ref :81: the 1-px border keeps a zero x-derivative
+  // (the per-column terms of the displacement -- cx = a0 x + a2, cy = a3 x + a5, gxc = a6 x -- are formed where a band
+  //  starts, from xf: three registers that do not have to live across the chunk loop)
+  const int xm1 = x - 1;
+  const unsigned ux_max = (unsigned)(W - 4), uy_max = (unsigned)(H - 4);
+  const bool can_sample = (W >= 4) & (H >= 4);  // else the unsigned range tests below would wrap
+  const bool w4 = (W & 3) == 0;                         // rows are 16-byte aligned -> 16-B LDS-DMA
+
+  // ---- plan: lane c (< 32) computes the I2 footprint of chunk c: x_lo | flags (bit 30 = stage through LDS, bit 29 =
+  //      skip, bit 28 = interior: no frame / border / invalid pixel in the chunk), which stays in lane c, and
+  //      y_lo | rows << 20, which moves to lane 32 + c of the same register (a tile has at most 32 chunks) ----
+  int plan = 0;
+  int plan_x = 0, plan_y = 0;
+  {
+    const int yc0 = y_begin + lane * CH;
+    const int rows = min(CH, y_end - yc0);
+    const bool skip = (lane >= nchunks) | (frame_on & ((yc0 + rows <= a.delta) | (yc0 >= H - a.delta)));
+    // pixels that take part with weight 1 and a full gradient stencil: outside the frame (or, without a frame, off
+    // the 1-px border where the reference keeps a zero derivative)
+    const int mrg = frame_on ? a.delta : 1;
+    bool interior = (rows == CH) & (yc0 >= mrg) & (yc0 + CH <= H - mrg) & (x_t0 >= mrg) & (x_t0 + kTileW <= W - mrg);
+    bool stage = false;
+    int x_lo = 0, y_lo = 0;
+    if constexpr (kB) {
+      // the image of the chunk rectangle under an affine / projective map is the convex quadrilateral of its
+      // mapped corners (denominator checked positive), so the corner positions bound every sampling position
+      const float xl = (float)x_t0, xr = (float)min(x_t0 + kTileW - 1, W - 1);
+      const float yt = (float)yc0, yb = (float)(yc0 + rows - 1);
+      float dxs[4], dys[4];
+      displacement<kProj>(A, xl, yt, dxs[0], dys[0]);
+      displacement<kProj>(A, xr, yt, dxs[1], dys[1]);
+      displacement<kProj>(A, xl, yb, dxs[2], dys[2]);
+      displacement<kProj>(A, xr, yb, dxs[3], dys[3]);
+      const float px0 = fminf(fminf(xl + dxs[0], xr + dxs[1]), fminf(xl + dxs[2], xr + dxs[3]));
+      const float px1 = fmaxf(fmaxf(xl + dxs[0], xr + dxs[1]), fmaxf(xl + dxs[2], xr + dxs[3]));
+      const float py0 = fminf(fminf(yt + dys[0], yt + dys[1]), fminf(yb + dys[2], yb + dys[3]));
+      const float py1 = fmaxf(fmaxf(yt + dys[0], yt + dys[1]), fmaxf(yb + dys[2], yb + dys[3]));
+      bool sane = (fabsf(px0) < 1.0e6f) & (fabsf(px1) < 1.0e6f) & (fabsf(py0) < 1.0e6f) & (fabsf(py1) < 1.0e6f);
+      if constexpr (kProj) {
+        const float g0 = fmaf(A[6], xl, A[7] * yt), g1 = fmaf(A[6], xr, A[7] * yt);
+        const float g2 = fmaf(A[6], xl, A[7] * yb), g3 = fmaf(A[6], xr, A[7] * yb);
+        sane = sane & (fminf(fminf(g0, g1), fminf(g2, g3)) > -0.5f);
+      }
+      if (sane) {
+        // taps of a pixel sampled at X: columns floor(X)-1 .. floor(X)+2; one more pixel of slack for fp32
+        // rounding; x_lo is rounded down to a multiple of 4 so that 16-byte copies stay aligned
+        x_lo = max(0, (int)floorf(px0) - 2) & ~3;
+        y_lo = max(0, (int)floorf(py0) - 2);
+        const int x_hi = min(W - 1, (int)floorf(px1) + 3);
+        const int y_hi = min(H - 1, (int)floorf(py1) + 3);
+        const int bw = x_hi - x_lo + 1, bh = y_hi - y_lo + 1;
+        stage = (bw >= 1) & (bh >= 1) & (bw <= P2) & (bh <= R2);
+        plan_y = bh << 20;
+        // every footprint inside the image with a pixel to spare: floor(X) - 1 >= 1 and floor(X) + 2 <= W - 2
+        interior = interior & (px0 >= 2.0f) & (px1 <= (float)(W - 4)) & (py0 >= 2.0f) & (py1 <= (float)(H - 4));
+      }
+      interior = interior & sane & stage;
+    }
+    plan_x = x_lo | (stage ? (1 << 30) : 0) | (skip ? (1 << 29) : 0) | (interior ? (1 << 28) : 0);
+    plan_y |= y_lo;
+    const int up = __shfl(plan_y, lane & 31, 64);  // lane 32 + c takes chunk c's word
+    plan = lane < 32 ? plan_x : up;
+  }
+  auto plan_px = [&](int k) { return __builtin_amdgcn_readlane(plan, k); };
+  auto plan_ylo = [&](int k) { return __builtin_amdgcn_readlane(plan, k + 32) & 0xFFFFF; };
+  auto plan_bh = [&](int k) { return __builtin_amdgcn_readlane(plan, k + 32) >> 20; };
+
+  // ---- LDS-DMA plumbing.  Buffer descriptors give hardware range checking (rows above / below the image are
+  // simply dropped, the LDS slot gets 0) and 32-bit offsets.  One wave-instruction moves RP whole tile rows: lane l
+  // carries float4 number (l % V) of row (l / V) of the group, V = float4 per tile row, so the only per-lane state is
+  // ONE byte offset per image (off1, off2), which does not depend on the chunk; everything else about a copy (first
+  // row, row shift, how many rows) is wave-uniform.  The tile's row groups are dealt round-robin to the 4 waves.
+  const auto rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)I1, 0, (int)(C * plane * sizeof(float)), 0x00020000);
+  constexpr int V1 = P1 / 4, V2 = P2 / 4;                       // float4 per buffer row
+  constexpr int RP1 = 64 / V1, RP2 = 64 / V2;                   // rows per wave-instruction
+  constexpr int NQ1 = (R1 + RP1 - 1) / RP1, NQ2 = (R2 + RP2 - 1) / RP2;  // row groups per tile
+  constexpr unsigned kPoison = 0x80000000u;                     // offset that is always out of range
+  unsigned off1, off2;
+  {
+    const int r1 = lane / V1, c1 = lane - r1 * V1, r2 = lane / V2, c2 = lane - r2 * V2;
+    const int xx = x_t0 - 4 + 4 * c1;
+    off1 = (xx >= 0 && xx < W) ? (unsigned)((r1 * W + 4 * c1 - 4) * 4) : kPoison;
+    off2 = (unsigned)((r2 * W + 4 * c2) * 4);
+  }
+
+  // issue the LDS-DMA copies of chunk k into buffer `buf` (no waits here).
+  // (Fetching only the rows a chunk does NOT share with its predecessor and moving the shared ones LDS -> LDS -- 9 of
+  //  the 25 I2 rows, 2 of the 18 I1 rows -- was built and measured: a quarter fewer L1 requests, but 9 % MORE time;
+  //  the move and its dependency sit in front of the copies.  profiles/r02_ablation.txt)
+  auto issue = [&](int k, int buf) {
+#if defined(ICA_ABLATE) && ICA_ABLATE == 2
+    return;  // timing-only build: no LDS-DMA
+#endif
+    const int px = plan_px(k), y_lo = plan_ylo(k);
+    float* b2 = lds + buf * TC::buf_floats;
+    float* b1 = b2 + C * P2 * R2;
+    const int yc0 = y_begin + k * CH;
+    if (w4) {
+      // a skipped (all-frame) chunk still issues its copies, with every lane out of range (the tile is zero-filled)
+      const bool skip = (px & (1 << 29)) != 0;
+      // may wrap below 0 (row -1): then out of range.  A skipped chunk gets an out-of-range base.
+      const unsigned base1 = skip ? 0x40000000u : (unsigned)(((yc0 - 1) * W + x_t0) * 4);
+#pragma unroll
+      for (int qq = 0; qq < (NQ1 + kWaves - 1) / kWaves; ++qq) {
+        const int q = wave + qq * kWaves;      // this wave's row group (wave-uniform)
+        // Lanes past the tile's last row must not take part at all: an out-of-range lane still writes its (zero) result
+        // to LDS, which would land in the neighbouring tile.
+        const int rows = min(RP1, R1 - RP1 * q);
+        if (q < NQ1 && lane < V1 * rows) {
+          float* dst = b1 + RP1 * q * P1;
+          unsigned u = base1 + (unsigned)(RP1 * q * W * 4);
+          asm volatile("" : "+s"(u));  // (opaque: the sum with off1 is formed here, not hoisted out of the chunk loop into a register)
+          const unsigned o = off1 + u;  // a poisoned offset stays out of range
+#pragma unroll
+          for (int c = 0; c < C; ++c)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (__attribute__((address_space(3))) void*)(dst + c * P1 * R1), 16,
+                                                     (int)(o + (unsigned)(c * plane * 4)), 0, 0, 0);
+        }
+      }
+      if constexpr (kB) {
+        const bool stage = !skip && (px & (1 << 30));
+        const int x_lo = px & 0xFFFFF;
+        const int bh = stage ? plan_bh(k) : 0;
+        // rows beyond the footprint fall outside this descriptor (a chunk that is not staged gets 0 rows) and are
+        // zero-filled
+        const auto rs2 = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)I2, 0, bh ? (int)(((size_t)(C - 1) * plane + (size_t)(y_lo + bh) * W) * 4) : 0, 0x00020000);
+        const unsigned base2 = (unsigned)((y_lo * W + x_lo) * 4);
+#pragma unroll
+        for (int qq = 0; qq < (NQ2 + kWaves - 1) / kWaves; ++qq) {
+          const int q = wave + qq * kWaves;
+          const int rows = min(RP2, R2 - RP2 * q);
+          if (q < NQ2 && lane < V2 * rows) {
+            float* dst = b2 + RP2 * q * P2;
+            unsigned u = base2 + (unsigned)(RP2 * q * W * 4);
+            asm volatile("" : "+s"(u));
+            const unsigned o = off2 + u;  // all P2 columns of a row are copied (a few more than needed)
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (__attribute__((address_space(3))) void*)(dst + c * P2 * R2), 16,
+                                                       (int)(o + (unsigned)(c * plane * 4)), 0, 0, 0);
+          }
+        }
+      }
+    } else {
+      if (px & (1 << 29)) return;
+      for (int r = wave; r < R1; r += kWaves) {
+        const int yy = yc0 - 1 + r;
+        if (yy < 0 || yy >= H) continue;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const float* src = I1 + c * plane + (size_t)yy * W + (x_t0 - 4);
+          float* dst = b1 + c * P1 * R1 + r * P1;
+          if ((x_t0 - 4 + lane >= 0) & (x_t0 - 4 + lane < W)) glds4(src + lane, dst);
+          if ((lane < P1 - 64) & (x_t0 + 60 + lane < W)) glds4(src + 64 + lane, dst + 64);
+        }
+      }
+      if (kB && (px & (1 << 30))) {
+        const int x_lo = px & 0xFFFFF;
+        for (int r = wave; r < R2; r += kWaves) {
+          const int yy = y_lo + r;
+          if (yy >= H) break;
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            const float* src = I2 + c * plane + (size_t)yy * W + x_lo;
+            float* dst = b2 + c * P2 * R2 + r * P2;
+            if (x_lo + lane < W) glds4(src + lane, dst);
+            if ((lane < P2 - 64) & (x_lo + 64 + lane < W)) glds4(src + 64 + lane, dst + 64);
+          }
+        }
+      }
+    }
+  };
+
+  if (!w4) {  // the dword copy path skips out-of-image lanes instead of zero-filling them: start from finite LDS
+    for (int i = threadIdx.x; i < kLdsFloats; i += kBlock) lds[i] = 0.f;
+    __syncthreads();
+  }
+
+  float m32[NMOM];
+#pragma unroll
+  for (int i = 0; i < NMOM; ++i) m32[i] = 0.f;
+
+  // wave-uniform values live in SGPRs between the bands (the fast band copies what it needs into VGPRs)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) A[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, A[i])));
+  lo = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lo)));
+  hi = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, hi)));
+  lam2 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lam2)));
+
+  // Ring protocol: chunk k+1 is in flight while chunk k is computed.  A wave's copies retire in order; the barrier
+  // makes every wave's part visible, and also means everyone has finished reading chunk k-1, whose buffer is the one
+  // chunk k+1 is about to overwrite.
+  static_assert(NBUF == 1 || NBUF == 2, "one or two staging buffers");
+  if (NBUF == 2) issue(0, 0);
+  for (int k = 0; k < nchunks; ++k) {
+    const int buf = (NBUF >= 2) ? (k % NBUF) : 0;
+    if (NBUF == 1) {
+      __syncthreads();  // everyone is done reading the single buffer
+      issue(k, 0);
+      __syncthreads();  // drains this wave's LDS-DMA (vmcnt(0)) and publishes chunk k
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (k + 1 < nchunks) issue(k + 1, (k + 1) % NBUF);
+    }
+
+    const int px = plan_px(k), y_lo = plan_ylo(k);
+    if (px & (1 << 29)) continue;
+    const bool staged = (px & (1 << 30)) != 0;
+    const bool interior = (px & (1 << 28)) != 0;
+    const int x_lo = px & 0xFFFFF;
+    const float* b2 = lds + buf * TC::buf_floats;
+    const float* b1 = b2 + C * P2 * R2;
+    const int yc0 = y_begin + k * CH;
+    const int yb0 = yc0 + wave * RW;
+    const float* i1p = b1 + (wave * RW) * P1 + lane + 4;  // row yb0-1 of this lane's column
+
+    // one pixel's contribution to the lane's y-moments: w = weight (1 for L2), ix2 / iy2 = 2*Ix, 2*Iy, di = residual.
+    // `yf` must be a VGPR value (fast band) or may be anything (careful band).
+    auto accumulate = [&](float w, const float* ix2, const float* iy2, const float* di, float yf) {
+      // one channel and a weighted sum: fold the weight into the gradient once (w Ix, w Iy) instead of scaling
+      // gx, gy, sxx, sxy, syy one by one
+      constexpr bool kFoldW = (C == 1) && kH;
+      float wix = 0.f, wiy = 0.f;
+      if constexpr (kFoldW) { wix = w * ix2[0]; wiy = w * iy2[0]; }
+      [[maybe_unused]] const float y2 = yf * yf;
+      if constexpr (kB) {
+        float gx = 0.f, gy = 0.f;
+        if constexpr (kFoldW) {
+          gx = wix * di[0];
+          gy = wiy * di[0];
+        } else {
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            gx = (c == 0) ? ix2[0] * di[0] : fmaf(ix2[c], di[c], gx);
+            gy = (c == 0) ? iy2[0] * di[0] : fmaf(iy2[c], di[c], gy);
+          }
+          if constexpr (kH) { gx *= w; gy *= w; }
+        }
+        m32[ML::ogx] += gx;
+        if constexpr (ML::mbx >= 1) m32[ML::ogx + 1] = fmaf(gx, yf, m32[ML::ogx + 1]);
+        m32[ML::ogy] += gy;
+        if constexpr (ML::mby >= 1) m32[ML::ogy + 1] = fmaf(gy, yf, m32[ML::ogy + 1]);
+        if constexpr (ML::mby >= 2) m32[ML::ogy + 2] = fmaf(gy, y2, m32[ML::ogy + 2]);
+      }
+      if constexpr (kH) {
+        float sxx = 0.f, sxy = 0.f, syy = 0.f;
+        if constexpr (kFoldW) {
+          sxx = wix * ix2[0];
+          sxy = wix * iy2[0];
+          syy = wiy * iy2[0];
+        } else {
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            sxx = (c == 0) ? ix2[0] * ix2[0] : fmaf(ix2[c], ix2[c], sxx);
+            sxy = (c == 0) ? ix2[0] * iy2[0] : fmaf(ix2[c], iy2[c], sxy);
+            syy = (c == 0) ? iy2[0] * iy2[0] : fmaf(iy2[c], iy2[c], syy);
+          }
+          sxx *= w; sxy *= w; syy *= w;
+        }
+        float yp[5];
+        yp[0] = 1.0f; yp[1] = yf; yp[2] = y2; yp[3] = y2 * yf; yp[4] = y2 * y2;
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+          if (b < ML::nxx) m32[ML::oxx + b] = (b == 0) ? m32[ML::oxx] + sxx : fmaf(sxx, yp[b], m32[ML::oxx + b]);
+          if (b < ML::nxy) m32[ML::oxy + b] = (b == 0) ? m32[ML::oxy] + sxy : fmaf(sxy, yp[b], m32[ML::oxy + b]);
+          if (b < ML::nyy) m32[ML::oyy + b] = (b == 0) ? m32[ML::oyy] + syy : fmaf(syy, yp[b], m32[ML::oyy + b]);
+        }
+      }
+    };
+
+    // ---------------------------------------------------------------------------------------------------------
+    // INTERIOR chunk: every pixel takes part, every footprint is inside I2 and inside the staged window.
+    // ---------------------------------------------------------------------------------------------------------
+    auto band_fast = [&]() {
+      // byte address of tap (0,0) of the pixel in row i  =  b2 + ((yb0 + i - 1 - y_lo) * P2 + (x - 1 - x_lo)) * 4
+      //                                                     + (floor(dy) * P2 + floor(dx)) * 4;
+      // the row part i * P2 * 4 is a compile-time LDS offset, the rest of the first line is computed once per chunk,
+      // and the second line is formed in fp32 (small integers, exact) with two multiply-adds: the integer forms
+      // (v_mul_i32_i24, v_mad) cost 2.7x a VOP2 on this chip
+      const int lds_b2 = (int)(unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)b2;
+      const float tap0f = (float)(lds_b2 + ((yb0 - 1 - y_lo) * P2 + (xm1 - x_lo)) * 4);
+      const float yf0 = in_vgpr((float)yb0);
+      [[maybe_unused]] const float cx = fmaf(A[0], xf, A[2]), cy = fmaf(A[3], xf, A[5]), gxc = A[6] * xf, nxf = -xf;
+      // wave-uniform operands, copied into VGPRs here (not kept in VGPRs across the chunk loop: registers are short)
+      [[maybe_unused]] const float a1v = pin_vgpr(A[1]), a4v = pin_vgpr(A[4]), a7v = pin_vgpr(A[7]);
+      [[maybe_unused]] const float hi_v = pin_vgpr(hi), lam2_v = pin_vgpr(lam2);
+      // I1: a row's up / down neighbours are the centre values of the rows before / after it, so the column is read
+      // once per row (rolling window of three values per channel)
+      float cu[C], cm[C], cd[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) { cm[c] = i1p[c * P1 * R1]; cd[c] = i1p[c * P1 * R1 + P1]; }
+#pragma unroll
+      for (int i = 0; i < RW; ++i) {
+        const float yf = i == 0 ? yf0 : yf0 + (float)i;  // exact (small integers); a VGPR because yf0 is one
+        float ix2[C], iy2[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const float* q = i1p + c * P1 * R1 + (i + 1) * P1;
+          cu[c] = cm[c]; cm[c] = cd[c]; cd[c] = q[P1];
+          ix2[c] = q[1] - q[-1];
+          iy2[c] = cd[c] - cu[c];
+        }
+        float di[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) di[c] = 0.f;
+        if constexpr (kB) {
+          float dxw = fmaf(a1v, yf, cx), dyw = fmaf(a4v, yf, cy);
+          if constexpr (kProj) {
+            const float g = fmaf(a7v, yf, gxc);
+            const float r = rcp_nr(1.0f + g);
+            dxw = fmaf(nxf, g, dxw) * r;
+            dyw = fmaf(-yf, g, dyw) * r;
+          }
+          const float flx = floorf(dxw), fly = floorf(dyw);
+          const float fx = dxw - flx, fy = dyw - fly;
+          float af;  // fly * (P2 * 4) + tap0f with the pitch as a literal (no register for it)
+          asm("v_fmamk_f32 %0, %1, %3, %2" : "=v"(af) : "v"(fly), "v"(tap0f), "n"(kPitchBits));
+          af = fmaf(flx, 4.0f, af);
+          const unsigned addr = (unsigned)af + (unsigned)(i * P2 * 4);
+          float wx[4], wy[4];
+          keys_weights(fx, wx);
+          keys_weights(fy, wy);
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            const __attribute__((address_space(3))) float* q =
+                (const __attribute__((address_space(3))) float*)(uintptr_t)(addr + (unsigned)(c * P2 * R2 * 4));
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float s = wx[0] * q[r * P2];
+              s = __builtin_fmaf(wx[1], q[r * P2 + 1], s);
+              s = __builtin_fmaf(wx[2], q[r * P2 + 2], s);
+              s = __builtin_fmaf(wx[3], q[r * P2 + 3], s);
+              v = (r == 0) ? wy[0] * s : __builtin_fmaf(wy[r], s, v);
+            }
+            di[c] = __builtin_amdgcn_fmed3f(v, lo, hi_v) - cm[c];  // clip (skimage warp), ref :114
+          }
+        }
+        float w = 1.0f;
+        if constexpr (kRobust) {
+          float t2 = di[0] * di[0];
+#pragma unroll
+          for (int c = 1; c < C; ++c) t2 = fmaf(di[c], di[c], t2);
+          w = rho_prime_t<RT>(t2, lam2_v);
+        }
+        accumulate(w, ix2, iy2, di, yf);
+#if ICA_ROW_FENCE
+        __builtin_amdgcn_sched_barrier(0);  // keep the rows apart: a row hoisted over the previous one's sums costs registers
+#endif
+      }
+    };
+
+    // ---------------------------------------------------------------------------------------------------------
+    // BORDER chunk (or one whose footprint was not staged): every test of the reference's pixel masks.
+    // ---------------------------------------------------------------------------------------------------------
+    auto band_careful = [&](auto staged_c) {
+      constexpr bool STAGED = decltype(staged_c)::value;
+      [[maybe_unused]] const float cx = fmaf(A[0], xf, A[2]), cy = fmaf(A[3], xf, A[5]), gxc = A[6] * xf;
+#pragma unroll 1   // the cold path: keep it small (registers, code), not fast
+      for (int i = 0; i < RW; ++i) {
+        const int y = yb0 + i;  // wave-uniform
+        const bool row_live = (y < y_end) & !(frame_on & ((y < a.delta) | (y >= H - a.delta)));
+        const float rmy = ((y >= 1) & (y <= H - 2)) ? 1.0f : 0.0f;  // ref :82: zero y-derivative on the border rows
+        const bool live = col_ok & row_live;
+        const float yf = (float)y;
+        float mid[C], ix2[C], iy2[C];  // 2*Ix, 2*Iy (the 1/2 is applied once per tile)
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const float* q = i1p + c * P1 * R1 + i * P1;
+          // unconditional LDS reads (the buffer only ever holds image values or the zeros the DMA writes for
+          // out-of-image elements, so masked-out lanes see finite values) and multiplicative 0/1 masks
+          mid[c] = q[P1];
+          ix2[c] = (q[P1 + 1] - q[P1 - 1]) * cmx;
+          iy2[c] = (q[2 * P1] - q[0]) * rmy;
+        }
+        float di[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) di[c] = 0.f;
+        if constexpr (kB) {
+          float dxw, dyw;
+          displacement_col<kProj>(A, cx, cy, gxc, xf, yf, dxw, dyw);
+          float flx = floorf(dxw), fly = floorf(dyw);
+          float fx = dxw - flx, fy = dyw - fly;
+          int ix = (int)flx, iy = (int)fly;
+          // A position within 2^-16 px of an integer: floor() decides whether the 4x4 footprint of a border pixel is
+          // inside the image, and fp32 (position good to ~1e-6 px) may land on the other side of the integer than the
+          // reference's float64.  Re-evaluate those lanes in float64 (rare: exact-integer translations, "round"
+          // parameters).  The interpolated VALUE is continuous across the integer, only the in/out decision is not.
+          const bool near_x = live & (fminf(fx, 1.0f - fx) < kNearInteger), near_y = live & (fminf(fy, 1.0f - fy) < kNearInteger);
+#ifndef ICA_NO_EXACT
+          if (near_x) exact_axis<TT, 0>(a.p + (size_t)pair * 8, ident, x, y, x, ix, fx);
+          if (near_y) exact_axis<TT, 1>(a.p + (size_t)pair * 8, ident, x, y, y, iy, fy);
+#endif
+          // 4x4 footprint inside the image (bicubic_interpolation.py:199, cval=nan), tested on the integer position of
+          // tap (0,0): ux = x0 - 1 in [0, W-4], uy = y0 - 1 in [0, H-4], one unsigned compare each.  An infinite position
+          // saturates in the conversion and lands outside; a NaN position converts to 0, may pass, and is caught by the
+          // finiteness test on the residual below (NaN weights -> NaN sample -> residual 0), which is what "outside"
+          // amounts to as well.
+          const int ux = ix + xm1, uy = iy + (y - 1);
+          const bool valid = live & can_sample & ((unsigned)ux <= ux_max) & ((unsigned)uy <= uy_max);
+          float wx[4], wy[4];
+          keys_weights(fx, wx);
+          keys_weights(fy, wy);
+          float iw[C];
+          if constexpr (STAGED) {
+            const int aoff_raw = __mul24(uy, P2) + ux - (y_lo * P2 + x_lo);
+            const int aoff = valid ? aoff_raw : 0;
+            const float* t = b2 + aoff;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+              const float* q = t + c * P2 * R2;
+              float v = 0.f;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                float s = wx[0] * q[r * P2];
+                s = __builtin_fmaf(wx[1], q[r * P2 + 1], s);
+                s = __builtin_fmaf(wx[2], q[r * P2 + 2], s);
+                s = __builtin_fmaf(wx[3], q[r * P2 + 3], s);
+                v = (r == 0) ? wy[0] * s : __builtin_fmaf(wy[r], s, v);
+              }
+              iw[c] = v;
+            }
+          } else {
+            const float* t = I2 + (valid ? (size_t)uy * W + ux : 0);
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+              const float* q = t + c * plane;
+              float v = 0.f;
+              if (valid) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  const float* rp = q + (size_t)r * W;
+                  float s = wx[0] * rp[0];
+                  s = __builtin_fmaf(wx[1], rp[1], s);
+                  s = __builtin_fmaf(wx[2], rp[2], s);
+                  s = __builtin_fmaf(wx[3], rp[3], s);
+                  v = (r == 0) ? wy[0] * s : __builtin_fmaf(wy[r], s, v);
+                }
+              }
+              iw[c] = v;
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            const float d = __builtin_amdgcn_fmed3f(iw[c], lo, hi) - mid[c];  // clip (skimage warp), ref :114
+            di[c] = (valid & (fabsf(d) <= 3.0e38f)) ? d : 0.0f;           // NaN / outside -> 0 (io.py:99)
+          }
+        }
+        float w = live ? 1.0f : 0.0f;  // pixels in the NaN frame contribute nothing (derivatives.py:84)
+        if constexpr (kRobust) {
+          float t2 = di[0] * di[0];
+#pragma unroll
+          for (int c = 1; c < C; ++c) t2 = fmaf(di[c], di[c], t2);
+          w = live ? rho_prime_t<RT>(t2, lam2) : 0.0f;  // rho'(0) where the warp is outside
+        }
+        if constexpr (!kH) {  // unweighted sums: the mask goes into the residual (one channel or three)
+#pragma unroll
+          for (int c = 0; c < C; ++c) di[c] *= w;
+        }
+        accumulate(w, ix2, iy2, di, yf);
+      }
+    };
+#if defined(ICA_ABLATE) && ICA_ABLATE == 1
+    if (a.delta < 0)  // timing-only build: staging and barriers only
+#endif
+    {
+#if defined(ICA_PROBE) && ICA_PROBE == 1   // register-pressure probe: fast band only
+      band_fast();
+#elif defined(ICA_PROBE) && ICA_PROBE == 2  // careful band only
+      if (staged) band_careful(std::true_type{});
+      else band_careful(std::false_type{});
+#else
+      if (staged & interior) band_fast();
+      else if (staged) band_careful(std::true_type{});
+      else band_careful(std::false_type{});
+#endif
+    }
+  }
+  // The y-moments of one lane's column over the whole tile (<= 64 rows per lane) stay in fp32 registers; they are
+  // promoted to fp64 here, before x powers up to x^4 are applied and 64 lanes x 4 waves x tiles are summed.
+  double m64[NMOM];
+#pragma unroll
+  for (int i = 0; i < NMOM; ++i) m64[i] = (double)m32[i];
+
+  // ---- fold the per-column moments into the tile's partial sums (fixed order) ----
+  __syncthreads();
+  double* mom = reinterpret_cast<double*>(lds);   // [NMOM][64] moments of the whole tile, per column
+  double* con = mom + NMOM * 64;                  // [N + NT][64] per-column contribution to each output sum
+  for (int wv = 0; wv < kWaves; ++wv) {           // waves take turns: deterministic wave order
+    if (wave == wv) {
+#pragma unroll
+      for (int i = 0; i < NMOM; ++i) {
+        if (wv == 0) mom[i * 64 + lane] = m64[i];
+        else mom[i * 64 + lane] += m64[i];
+      }
+    }
+    __syncthreads();
+  }
+  // every lane applies its own x powers; the (N + NT) outputs are dealt round-robin to the 4 waves.  When the
+  // contributions of all outputs do not fit the LDS next to the moments (robust homography), they are produced and
+  // summed in two halves.
+  constexpr int kOut = N + NT;
+  constexpr int kHalf = kFoldSplit ? (kOut + 1) / 2 : kOut;
+#pragma unroll
+  for (int part = 0; part < (kFoldSplit ? 2 : 1); ++part) {
+    const int e_lo = part * kHalf, e_hi = (part == 0 ? kHalf : kOut);
+    {
+      double xp[5];
+      xp[0] = 1.0;
+#pragma unroll
+      for (int i = 1; i < 5; ++i) xp[i] = xp[i - 1] * (double)x;
+      auto term = [&](Mono j1, Mono j2, int base) -> double {  // j1 * j2 * moment, all indices compile-time
+        return (double)(j1.c * j2.c) * xp[j1.a + j2.a] * mom[(base + j1.b + j2.b) * 64 + lane];
+      };
+      int e = 0;
+#pragma unroll
+      for (int k = 0; k < N; ++k) {   // b_k (halved: the gradients were accumulated as 2*Ix, 2*Iy)
+        if (kB && (e & 3) == wave && e >= e_lo && e < e_hi) {
+          constexpr Mono one{1, 0, 0};
+          const Mono jx = jac_x(TT, k), jy = jac_y(TT, k);
+          double v = 0.0;
+          if (jx.c) v += term(jx, one, ML::ogx);
+          if (jy.c) v += term(jy, one, ML::ogy);
+          con[(e - e_lo) * 64 + lane] = 0.5 * v;
+        }
+        ++e;
+      }
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+#pragma unroll
+        for (int m = k; m < N; ++m) {  // H_km (quartered)
+          if (kH && (e & 3) == wave && e >= e_lo && e < e_hi) {
+            const Mono jxk = jac_x(TT, k), jyk = jac_y(TT, k), jxm = jac_x(TT, m), jym = jac_y(TT, m);
+            double v = 0.0;
+            if (jxk.c && jxm.c) v += term(jxk, jxm, ML::oxx);
+            if (jxk.c && jym.c) v += term(jxk, jym, ML::oxy);
+            if (jyk.c && jxm.c) v += term(jyk, jxm, ML::oxy);
+            if (jyk.c && jym.c) v += term(jyk, jym, ML::oyy);
+            con[(e - e_lo) * 64 + lane] = 0.25 * v;
+          }
+          ++e;
+        }
+      }
+    }
+    __syncthreads();
+    {
+      const int t = threadIdx.x;
+      const int e = e_lo + (t >> 2), q = t & 3;   // 4 threads per output, 16 columns each, then a fixed 2-step tree
+      double val = 0.0;
+      const bool have = (e < e_hi) && ((e < N) ? kB : (e < N + NT ? kH : false));
+      if (have) {
+#pragma unroll
+        for (int l = 0; l < 16; ++l) val += con[(e - e_lo) * 64 + q * 16 + l];
+      }
+      val += __shfl_down(val, 2, 64);
+      val += __shfl_down(val, 1, 64);
+      if (q == 0 && have) {
+        double* out = a.partials + ((size_t)pair_slot * ntiles + tile_id) * kAccStride;  // indexed by launch slot
+        double* dst = out + (e < N ? e : kMaxN + (e - N));
+        *dst = val;
+      }
+    }
+    if (kFoldSplit && part == 0) __syncthreads();
+  }
+}
+
+}  // namespace ica

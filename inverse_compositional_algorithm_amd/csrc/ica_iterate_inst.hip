@@ -1,0 +1,46 @@
+// Instantiations of the fused iteration kernel for ONE transform type (-DICA_INST_TT=1..5): 2 channel counts x
+// (L2, L2-first, Hessian + 4 robust error functions).  build.py compiles this file five times, in parallel.
+#include "ica_iterate.hpp"
+#include "ica_iterate_launch.hpp"
+
+#ifndef ICA_INST_TT
+#error "compile with -DICA_INST_TT=<transform type 1..5>"
+#endif
+
+namespace ica {
+namespace {
+
+template <int TT, int MODE, int RT>
+void launch_c(int channels, unsigned blocks, hipStream_t st, const LevelArgs& a) {
+  if (channels == 1) hipLaunchKernelGGL((ica_iterate_kernel<TT, MODE, 1, RT>), dim3(blocks), dim3(kBlock), 0, st, a);
+  else hipLaunchKernelGGL((ica_iterate_kernel<TT, MODE, 3, RT>), dim3(blocks), dim3(kBlock), 0, st, a);
+}
+
+template <int TT>
+void launch_tt(int mode, int channels, int robust_type, unsigned blocks, hipStream_t st, const LevelArgs& a) {
+  switch (mode) {
+    case kModeL2: launch_c<TT, kModeL2, ICA_QUADRATIC>(channels, blocks, st, a); break;
+    case kModeL2First: launch_c<TT, kModeL2First, ICA_QUADRATIC>(channels, blocks, st, a); break;
+    case kModeHessian: launch_c<TT, kModeHessian, ICA_QUADRATIC>(channels, blocks, st, a); break;
+    default:
+      // the robust error function is a template argument of the kernel (no branches in its pixel loop)
+      switch (robust_type) {
+        case ICA_TRUNCATED_QUADRATIC: launch_c<TT, kModeRobust, ICA_TRUNCATED_QUADRATIC>(channels, blocks, st, a); break;
+        case ICA_GERMAN_MCCLURE: launch_c<TT, kModeRobust, ICA_GERMAN_MCCLURE>(channels, blocks, st, a); break;
+        case ICA_LORENTZIAN: launch_c<TT, kModeRobust, ICA_LORENTZIAN>(channels, blocks, st, a); break;
+        case ICA_CHARBONNIER: launch_c<TT, kModeRobust, ICA_CHARBONNIER>(channels, blocks, st, a); break;
+        default: break;  // QUADRATIC never takes the robust schedule (ica_solve_batch_dev)
+      }
+  }
+}
+
+}  // namespace
+
+#define ICA_CAT2(a, b) a##b
+#define ICA_CAT(a, b) ICA_CAT2(a, b)
+void ICA_CAT(launch_iterate_tt, ICA_INST_TT)(int mode, int channels, int robust_type, unsigned blocks, hipStream_t st,
+                                             const LevelArgs& a) {
+  launch_tt<ICA_INST_TT>(mode, channels, robust_type, blocks, st, a);
+}
+
+}  // namespace ica

@@ -1,170 +1,10 @@
-// HIP kernels of the inverse-compositional hot path for gfx950 (wave64).
-//
-// Data layout (HBM): images float32 planar [B][C][H][W]; per-pair state float64.
-// The reference materialises gradient, Jacobian and steepest-descent tensors (192 B/pixel for
-// C=3, n=8).  Here nothing but the two images is ever read per iteration: gradients, Jacobian rows,
-// steepest-descent values and robust weights are recomputed in registers.
+// HIP kernels of the inverse-compositional hot path other than the fused iteration kernel (ica_iterate.hpp): the
+// direct-gather cross-check kernel, per-pair solve / update, level bookkeeping, warp write-out, transform_image,
+// min/max, the pyramid passes and the per-operator test hooks.  Included by ONE translation unit (ica_api.hip).
 #pragma once
-#include <hip/hip_runtime.h>
-
-#include <type_traits>
-
-#include "ica_math.hpp"
+#include "ica_common.hpp"
 
 namespace ica {
-
-constexpr int kBlock = 256;   // 4 waves
-constexpr int kTileW = 64;    // one lane per column of a tile
-constexpr int kWaves = kBlock / 64;
-constexpr int kFlush = 8;     // fp32 partial sums are promoted to fp64 every kFlush pixels per thread
-
-enum Mode { kModeL2 = 0, kModeRobust = 1, kModeHessian = 2, kModeL2First = 3 };
-
-#ifndef ICA_FLAT_BELOW
-#define ICA_FLAT_BELOW 8
-#endif
-
-struct LevelArgs {
-  const float* I1;
-  const float* I2;
-  int H, W;
-  int tiles_x, tiles_y, tile_h;
-  int delta, nanif;
-  int robust_type;
-  const double* p;          // [B][8]
-  const double* lambda_it;  // [B]
-  const float* minmax;      // [B][2] clip range of I2 at this level
-  const int* act_list;      // current active pairs (nullptr: pair index = slot)
-  const int* act_count;   // kListShards shard counters (see list_total / list_entry)
-  int list_cap;           // entries per shard
-  int n_pairs;              // pairs covered by this launch (the bound when act_list == nullptr; picks the block map)
-  int* host_slot;           // nullable, host-visible: receives *act_count (pairs entering this iteration)
-  double* partials;         // [slot][tiles][kAccStride]; slot = index into the active list (= pair without a list)
-};
-
-// ---- active-pair lists ------------------------------------------------------------------------------
-// A list of the pairs that enter an iteration is kept in kListShards shards; a producer (the solve of workgroup /
-// slot b) appends to shard b & 7 with an atomicAdd on THAT shard's counter.  1024 workgroups adding to one counter
-// serialise on it (measured: +7.5 us per solve launch); eight counters on eight cache lines do not.  A shard never
-// receives more than ceil(B / 8) entries, so the eight shards together are no larger than one flat list.
-// Consumers number the entries shard after shard.
-constexpr int kFlatMapBelow = ICA_FLAT_BELOW;  // launches of fewer pairs use the flat block map (ica_accumulate2.hpp)
-constexpr int kListShards = 8;
-constexpr int kShardStride = 32;  // ints between two shard counters: one 128-byte line each
-__host__ __device__ inline int list_shard_cap(int batch) { return (batch + kListShards - 1) / kListShards; }
-__device__ __forceinline__ int list_total(const int* cnt) {
-  int t = 0;
-#pragma unroll
-  for (int s = 0; s < kListShards; ++s) t += cnt[s * kShardStride];
-  return t;
-}
-// entry number `slot` of the list (caller has checked slot < list_total)
-__device__ __forceinline__ int list_entry(const int* list, const int* cnt, int cap, int slot) {
-  int shard = 0;
-#pragma unroll
-  for (int s = 0; s < kListShards - 1; ++s) {
-    const int c = cnt[s * kShardStride];
-    if (shard == s && slot >= c) { slot -= c; shard = s + 1; }
-  }
-  return list[shard * cap + slot];
-}
-__device__ __forceinline__ void list_append(int* list, int* cnt, int cap, int producer, int value) {
-  const int shard = producer & (kListShards - 1);
-  const int idx = atomicAdd(cnt + shard * kShardStride, 1);
-  list[shard * cap + idx] = value;
-}
-__device__ __forceinline__ void list_clear(int* cnt) {
-#pragma unroll
-  for (int s = 0; s < kListShards; ++s) cnt[s * kShardStride] = 0;
-}
-
-
-template <int TT> struct NP;
-template <> struct NP<ICA_TRANSLATION> { static constexpr int n = 2; };
-template <> struct NP<ICA_EUCLIDEAN> { static constexpr int n = 3; };
-template <> struct NP<ICA_SIMILARITY> { static constexpr int n = 4; };
-template <> struct NP<ICA_AFFINITY> { static constexpr int n = 6; };
-template <> struct NP<ICA_HOMOGRAPHY> { static constexpr int n = 8; };
-
-// Steepest-descent row  D[k] = Ix*Jx[k] + Iy*Jy[k]  (image_optimisation.py:190-192) with the Jacobian
-// rows of derivatives.py:33-68; x = column, y = row, integer pixel indices.
-template <int TT>
-__device__ __forceinline__ void steepest_descent(float ix, float iy, float x, float y, float* D) {
-  if constexpr (TT == ICA_TRANSLATION) {
-    D[0] = ix; D[1] = iy;
-  } else if constexpr (TT == ICA_EUCLIDEAN) {
-    D[0] = ix; D[1] = iy; D[2] = x * iy - y * ix;
-  } else if constexpr (TT == ICA_SIMILARITY) {
-    D[0] = ix; D[1] = iy; D[2] = x * ix + y * iy; D[3] = x * iy - y * ix;
-  } else if constexpr (TT == ICA_AFFINITY) {
-    D[0] = ix; D[1] = iy; D[2] = x * ix; D[3] = y * ix; D[4] = x * iy; D[5] = y * iy;
-  } else {
-    const float s = x * ix + y * iy;
-    D[0] = x * ix; D[1] = y * ix; D[2] = ix; D[3] = x * iy; D[4] = y * iy; D[5] = iy;
-    D[6] = -x * s; D[7] = -y * s;
-  }
-}
-
-// Displacement (dx, dy) = W(x;p) - x in fp32.  Working on the displacement instead of the absolute
-// position keeps every term small (|d| is tens of pixels at most), so fp32 resolves the sampling
-// position to ~1e-6 px even at x ~ 2000.
-template <bool PROJ>
-__device__ __forceinline__ void displacement(const float* a, float x, float y, float& dx, float& dy) {
-  float nx = fmaf(a[0], x, fmaf(a[1], y, a[2]));
-  float ny = fmaf(a[3], x, fmaf(a[4], y, a[5]));
-  if constexpr (PROJ) {
-    const float g = fmaf(a[6], x, a[7] * y);
-    const float r = rcp_nr(1.0f + g);
-    nx = (nx - x * g) * r;
-    ny = (ny - y * g) * r;
-  }
-  dx = nx;
-  dy = ny;
-}
-
-__device__ __forceinline__ void keys_weights(float t, float* w) {
-  // Catmull-Rom (Keys a = -1/2), the cubic of skimage's _warp_fast / bicubic_interpolation.py:39-41
-  w[0] = ((-0.5f * t + 1.0f) * t - 0.5f) * t;
-  w[1] = (1.5f * t - 2.5f) * t * t + 1.0f;
-  w[2] = ((-1.5f * t + 2.0f) * t + 0.5f) * t;
-  w[3] = (0.5f * t - 0.5f) * t * t;
-}
-
-// Bicubic sample of C planes at (x+dx, y+dy); false (and nothing written) when any of the 16 taps is
-// outside the image -- the reference's NaN (bicubic_interpolation.py:199, cval=nan).  The result is
-// clipped to [lo, hi] as skimage.transform.warp(clip=True) does.
-template <int C>
-__device__ __forceinline__ bool warp_sample(const float* __restrict__ img, int H, int W, int x, int y,
-                                            float dx, float dy, float lo, float hi, float* out) {
-  const float flx = floorf(dx), fly = floorf(dy);
-  const int x0 = x + (int)flx, y0 = y + (int)fly;
-  const bool ok = (x0 >= 1) & (x0 <= W - 3) & (y0 >= 1) & (y0 <= H - 3);
-  if (!ok) return false;
-  float wx[4], wy[4];
-  keys_weights(dx - flx, wx);
-  keys_weights(dy - fly, wy);
-  const size_t plane = (size_t)H * W;
-  const float* base = img + (size_t)(y0 - 1) * W + (x0 - 1);
-#pragma unroll
-  for (int c = 0; c < C; ++c) {
-    const float* q = base + c * plane;
-    float v = 0.0f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float* row = q + (size_t)r * W;
-      const float s = wx[0] * row[0] + wx[1] * row[1] + wx[2] * row[2] + wx[3] * row[3];
-      v = fmaf(wy[r], s, v);
-    }
-    out[c] = fminf(fmaxf(v, lo), hi);
-  }
-  return true;
-}
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;  // valid in lane 0
-}
 
 // The fused per-iteration pass (ref :111-117 / :227-244 and the setup Hessian :96-102):
 //   MODE kModeL2      b = sum DIJ^T DI                      over F & V(p)
@@ -238,7 +78,7 @@ __global__ __launch_bounds__(kBlock) void ica_accumulate_kernel(LevelArgs a) {
         float iw[C];
         if constexpr (kB) {
           displacement<kProj>(A, xf, yf, dxw, dyw);
-          valid = warp_sample<C>(I2, H, W, x, y, dxw, dyw, lo, hi, iw);
+          valid = warp_sample<C>(I2, H, W, x, y, dxw, dyw, lo, hi, iw, a.p + (size_t)pair * 8, TT);
         }
         const float* c1 = I1 + (size_t)y * W + x;
 #pragma unroll
@@ -620,7 +460,8 @@ __global__ __launch_bounds__(kBlock) void ica_warp_kernel(const float* __restric
   const size_t plane = (size_t)H * W;
   const size_t base = (size_t)pair * C * plane;
   float v[C];
-  const bool ok = warp_sample<C>(I2 + base, H, W, x, y, dx, dy, minmax[pair * 2], minmax[pair * 2 + 1], v);
+  const bool ok = warp_sample<C>(I2 + base, H, W, x, y, dx, dy, minmax[pair * 2], minmax[pair * 2 + 1], v,
+                                 p + (size_t)pair * 8, tt);
   const float nanv = __builtin_nanf("");
 #pragma unroll
   for (int c = 0; c < C; ++c) {

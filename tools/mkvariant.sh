@@ -1,6 +1,9 @@
 #!/bin/bash
 # usage: tools/mkvariant.sh <name> <flags...>  -> tools/abl/lib_<name>.so (select with ICA_LIB=tools/abl/lib_<name>.so)
 name=$1; shift
-mkdir -p "$(dirname "$0")/abl"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -o "$(dirname "$0")/abl/lib_$name.so" \
-  "$(dirname "$0")/../inverse_compositional_algorithm_amd/csrc/ica_api.hip" "$@" 2>&1 | grep -E "error|static assertion" 
+root="$(cd "$(dirname "$0")/.." && pwd)"
+mkdir -p "$root/tools/abl"
+cd "$root" && python3 -c "
+import sys
+from inverse_compositional_algorithm_amd import build
+print(build.build_variant('$root/tools/abl/lib_$name.so', sys.argv[1:]))" "$@"

@@ -11,7 +11,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for fn in f:
     for r in csv.DictReader(open(fn)):
         k = r['Kernel_Name']
-        if 'accumulate' not in k: continue
+        if 'accumulate' not in k and 'iterate' not in k: continue
         agg[k.split('(')[0][-40:]][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, d in agg.items():
     print(k)

@@ -39,9 +39,9 @@
         "v_mov_b32 v60, 0\n v_mov_b32 v61, 0\n v_mov_b32 v62, 0\n v_mov_b32 v63, 0\n"                       \
         "v_mov_b32 v64, 0\n v_mov_b32 v65, 0\n v_mov_b32 v66, 0\n v_mov_b32 v67, 0\n"                       \
         "v_mov_b32 v68, 0\n v_mov_b32 v69, 0\n v_mov_b32 v70, 0\n v_mov_b32 v71, 0\n"                       \
-        "v_mov_b32 v72, %2\n v_mov_b32 v73, %3\n"                                                           \
+        "v_mov_b32 v72, %2\n v_mov_b32 v73, %3\n v_lshlrev_b32 v74, 1, %3\n v_and_b32 v74, 0x1ff0, v74\n"                                                           \
         "s_mov_b32 s20, 1.0\n s_mov_b32 s21, 0.5\n s_mov_b32 s22, 2.0\n s_mov_b32 s23, 4.0\n"               \
-        "s_mov_b32 s24, %4\n"                                                                               \
+        "s_mov_b32 s24, %4\n s_mov_b32 s26, 0x55555555\n s_mov_b32 s27, 0x33333333\n"                                                                               \
         "s_mov_b32 vcc_lo, 0x55555555\n s_mov_b32 vcc_hi, 0x55555555\n"                                                               \
         "s_waitcnt vmcnt(0) lgkmcnt(0)\n s_barrier\n"                                                       \
         "s_memtime %0\n s_waitcnt lgkmcnt(0)\n"                                                             \
@@ -55,7 +55,7 @@
           "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", \
           "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", \
           "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", \
-          "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73");               \
+          "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75");               \
     if ((threadIdx.x & 63) == 0) out[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;                        \
     if (lds[threadIdx.x] < -1.f) out[0] = 0;                                                                \
   }
@@ -108,6 +108,28 @@
 #define ALIGNB(d, a, b, c) "v_alignbyte_b32 v" S_(d) ", v" S_(a) ", v" S_(b) ", v" S_(c) "\n"
 #define CMPU(d, a, b, c) "v_cmp_ge_u32 vcc, v" S_(a) ", v" S_(b) "\n"
 #define FMAMIX(d, a, b, c) "v_fma_mix_f32 v" S_(d) ", v" S_(a) ", v" S_(b) ", v" S_(c) " op_sel_hi:[0,1,0]\n"
+
+#define MULE64(d, a, b, c) "v_mul_f32_e64 v" S_(d) ", v" S_(a) ", v" S_(b) "\n"
+#define MULC(d, a, b, c) "v_mul_f32 v" S_(d) ", 0.5, v" S_(b) "\n"
+#define ADDC(d, a, b, c) "v_add_f32 v" S_(d) ", 1.0, v" S_(b) "\n"
+#define SUBF(d, a, b, c) "v_sub_f32 v" S_(d) ", v" S_(a) ", v" S_(b) "\n"
+#define MAXF(d, a, b, c) "v_max_f32 v" S_(d) ", v" S_(a) ", v" S_(b) "\n"
+#define CNDS(d, a, b, c) "v_cndmask_b32_e64 v" S_(d) ", v" S_(a) ", v" S_(b) ", s[26:27]\n"
+#define CMPE64(d, a, b, c) "v_cmp_ge_u32_e64 s[26:27], v" S_(a) ", v" S_(b) "\n"
+#define CMPF(d, a, b, c) "v_cmp_le_f32 vcc, v" S_(a) ", v" S_(b) "\n"
+#define LSHL(d, a, b, c) "v_lshlrev_b32 v" S_(d) ", 2, v" S_(a) "\n"
+#define ANDB(d, a, b, c) "v_and_b32 v" S_(d) ", v" S_(a) ", v" S_(b) "\n"
+#define MULI24(d, a, b, c) "v_mul_i32_i24 v" S_(d) ", v" S_(a) ", v" S_(b) "\n"
+#define MADI24(d, a, b, c) "v_mad_i32_i24 v" S_(d) ", v" S_(a) ", v" S_(b) ", v" S_(c) "\n"
+#define CVTFI(d, a, b, c) "v_cvt_f32_i32 v" S_(d) ", v" S_(a) "\n"
+#define RSQ(d, a, b, c) "v_rsq_f32 v" S_(d) ", v" S_(a) "\n"
+#define MOV(d, a, b, c) "v_mov_b32 v" S_(d) ", v" S_(a) "\n"
+#define FMANEG(d, a, b, c) "v_fma_f32 v" S_(d) ", -v" S_(a) ", v" S_(b) ", v" S_(c) "\n"
+#define FMACC(d, a, b, c) "v_fmac_f32 v" S_(d) ", 0.5, v" S_(b) "\n"
+#define CNDMIX(d, a, b, c) "v_cndmask_b32 v" S_(d) ", v" S_(a) ", v" S_(b) ", vcc\n v_mul_f32 v" S_(d) ", v" S_(a) ", v" S_(b) "\n v_add_f32 v" S_(d) ", v" S_(a) ", v" S_(b) "\n v_mul_f32 v" S_(d) ", v" S_(b) ", v" S_(c) "\n"
+#define DSR32ADJ(d, a, b, c) "ds_read_b32 v" S_(d) ", v72 offset:" S_(a) "*4\n"
+#define DSR32CONF(d, a, b, c) "ds_read_b32 v" S_(d) ", v73 offset:" S_(a) "*16\n"
+#define DSR128(d, a, b, c) "ds_read_b128 v[" S_(d) ":" S_(d) "+3], v74 offset:" S_(a) "*16\n"
 // LDS reads into v40.. (v72 = lane*4 + wave*4096: conflict-free dwords; v73 = lane*8 + ...: for 8-byte reads)
 #define DSR32(d, a, b, c) "ds_read_b32 v" S_(d) ", v72 offset:" S_(a) "*16\n"
 #define DSR2(d, a, b, c) "ds_read2_b32 v[" S_(d) ":" S_(d) "+1], v72 offset0:" S_(a) " offset1:" S_(a) "+1\n"
@@ -160,6 +182,29 @@ KERNEL(k_mix_16fmac_16mul2, B16(FMAC) B16(MUL2), 32)
 KERNEL(k_mix_16fma3_16mul2, B16(FMA3) B16(MUL2), 32)
 KERNEL(k_mix_16pkfma_16mul2, B16P(PKFMA) B16(MUL2), 32)
 
+
+KERNEL(k_mul_e64, B16(MULE64), 16)
+KERNEL(k_mul_const, B16(MULC), 16)
+KERNEL(k_add_const, B16(ADDC), 16)
+KERNEL(k_sub, B16(SUBF), 16)
+KERNEL(k_max, B16(MAXF), 16)
+KERNEL(k_cndmask_sgpr, B16(CNDS), 16)
+KERNEL(k_cmp_e64, B16(CMPE64), 16)
+KERNEL(k_cmp_f32, B16(CMPF), 16)
+KERNEL(k_lshl, B16(LSHL), 16)
+KERNEL(k_and, B16(ANDB), 16)
+KERNEL(k_mul_i24, B16(MULI24), 16)
+KERNEL(k_mad_i24, B16(MADI24), 16)
+KERNEL(k_cvt_f32_i32, B16(CVTFI), 16)
+KERNEL(k_rsq, B16(RSQ), 16)
+KERNEL(k_mov, B16(MOV), 16)
+KERNEL(k_fma_neg, B16(FMANEG), 16)
+KERNEL(k_fmac_const, B16(FMACC), 16)
+KERNEL(k_cndmask_1in4, B16(CNDMIX), 64)
+KERNEL(k_ds_read_b32_adj, B16(DSR32ADJ) "s_waitcnt lgkmcnt(0)\n", 16)
+KERNEL(k_ds_read_b32_2way, B16(DSR32CONF) "s_waitcnt lgkmcnt(0)\n", 16)
+KERNEL(k_ds_read_b128, REP4(DSR128(40, 1, 0, 0) DSR128(44, 2, 0, 0) DSR128(48, 3, 0, 0) DSR128(52, 4, 0, 0)) "s_waitcnt lgkmcnt(0)\n", 16)
+
 typedef void (*kern_t)(unsigned long long*, int);
 struct Entry { const char* name; kern_t fn; int ninstr; };
 #define E(n, c) {#n, n, c}
@@ -173,27 +218,40 @@ int main(int argc, char** argv) {
       E(k_add_u32, 16), E(k_dpp_wave_shr, 16), E(k_dpp_sub, 16), E(k_dpp_row_shr, 16), E(k_readlane, 16), E(k_cvt_ubyte, 16),
       E(k_perm, 16), E(k_alignbyte, 16), E(k_cmp_u32, 16), E(k_fma_mix, 16), E(k_ds_read_b32, 16), E(k_ds_read2_b32, 16),
       E(k_ds_read_b64, 16), E(k_mix_16fmac_16ds32, 32), E(k_mix_32fmac_16ds32, 48), E(k_mix_64fmac_16ds2, 80),
-      E(k_mix_16fmac_16mul2, 32), E(k_mix_16fma3_16mul2, 32), E(k_mix_16pkfma_16mul2, 32)};
+      E(k_mix_16fmac_16mul2, 32), E(k_mix_16fma3_16mul2, 32), E(k_mix_16pkfma_16mul2, 32),
+      E(k_mul_e64, 16), E(k_mul_const, 16), E(k_add_const, 16), E(k_sub, 16), E(k_max, 16), E(k_cndmask_sgpr, 16),
+      E(k_cmp_e64, 16), E(k_cmp_f32, 16), E(k_lshl, 16), E(k_and, 16), E(k_mul_i24, 16), E(k_mad_i24, 16),
+      E(k_cvt_f32_i32, 16), E(k_rsq, 16), E(k_mov, 16), E(k_fma_neg, 16), E(k_fmac_const, 16), E(k_cndmask_1in4, 64),
+      E(k_ds_read_b32_adj, 16), E(k_ds_read_b32_2way, 16), E(k_ds_read_b128, 16)};
+  if (argc > 1) es.erase(es.begin(), es.begin() + atoi(argv[1]));
   const int iters = 4000;
   unsigned long long* d;
   (void)hipMalloc(&d, sizeof(unsigned long long) * 4 * 256 * 8);
   std::vector<unsigned long long> h(4 * 256 * 8);
   printf("%-24s", "cycles/instr: wave|SIMD");
-  const int Ws[] = {1, 2, 4, 6, 8};
-  for (int w : Ws) printf("      W=%d      ", w);
+  const int Ws[] = {2, 4, 5, 6};
+  for (int w : Ws) printf("        W=%d           ", w);
   printf("\n");
   for (auto& e : es) {
     printf("%-24s", e.name);
     for (int w : Ws) {
       const int blocks = 256 * w;
       hipLaunchKernelGGL(e.fn, dim3(blocks), dim3(256), 0, 0, d, 10);
+      hipEvent_t e0, e1;
+      (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+      (void)hipEventRecord(e0, 0);
       hipLaunchKernelGGL(e.fn, dim3(blocks), dim3(256), 0, 0, d, iters);
+      (void)hipEventRecord(e1, 0);
       if (hipDeviceSynchronize() != hipSuccess) { printf(" launch failed\n"); return 1; }
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      const double ns_per = ms * 1e6 / ((double)iters * e.ninstr * w);  // wall ns per wave-instruction per SIMD
+      (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
       (void)hipMemcpy(h.data(), d, sizeof(unsigned long long) * 4 * blocks, hipMemcpyDeviceToHost);
       std::vector<unsigned long long> v(h.begin(), h.begin() + 4 * blocks);
       std::sort(v.begin(), v.end());
       const double med = (double)v[v.size() / 2] / ((double)iters * e.ninstr);
-      printf("  %6.2f|%5.2f ", med, med / w);
+      printf("  %6.2f|%5.2f|%4.2fns ", med, med / w, ns_per);
     }
     printf("\n");
     fflush(stdout);
