@@ -16,7 +16,7 @@ Pairs are independent, so N GPUs run N shards of the same per-GPU batch with no 
 
 The headline workload is BASELINE.json configs[3] (1024 pairs of 1024x1024, homography, Lorentzian, 4 scales): the
 configuration the 70 %-of-roofline target is quoted on, whose iteration kernel is the fused
-warp + steepest-descent + Hessian pass with the robust weight, `ica_accumulate2_kernel<5, 1, 1>`.  At N = 1 the same
+warp + steepest-descent + Hessian pass with the robust weight, `ica_iterate_kernel<5, 1, 1, 3>`.  At N = 1 the same
 JSON line carries `per_config`: shorter runs of configs[1], configs[2] and the per-GPU shard of configs[4].
 """
 from __future__ import annotations
@@ -46,7 +46,9 @@ CONFIGS = {
             name="configs[4]: 1024 pairs/GPU 1920x1080x3, HOMOGRAPHY, LORENTZIAN, 5 scales"),
 }
 DEFAULT_CONFIG = 4                 # BASELINE configs[3]
-SIDE_CONFIGS = ((2, 3), (3, 3), (5, 2))   # (config id, timed steps) of the per_config entries
+# (config id, timed steps, image storage) of the per_config entries; the last one is the headline workload again with
+# its level-0 images stored as uint8, reported under both byte conventions
+SIDE_CONFIGS = ((2, 3, "f32"), (3, 3, "f32"), (5, 2, "f32"), (4, 3, "u8"))
 SIDE_DEADLINE_S = 330.0            # no side config is started later than this after process start
 IN_FLIGHT_DEFAULT = 1
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
@@ -56,7 +58,7 @@ T_START = time.perf_counter()
 
 def kernel_key(cfg):
     """Template arguments <transform, mode, channels> of the steady-state iteration kernel of a workload."""
-    return f"<{cfg['transform']}, {1 if cfg['robust'] else 0}, {cfg['C']}>"
+    return f"<{cfg['transform']}, {1 if cfg['robust'] else 0}, {cfg['C']}, {cfg['robust']}>"
 
 
 def measured_traffic(cfg):
@@ -186,7 +188,7 @@ def run_stub(args, info, sharding):
 
 # ---- one measured workload ---------------------------------------------------------------------------------
 
-def measure(args, info, sharding, cfg_id, steps, warmup, D, batch=0):
+def measure(args, info, sharding, cfg_id, steps, warmup, D, batch=0, storage="f32"):
     """Generate this rank's shard of `cfg_id`, run `warmup` untimed and `steps` timed solves between barriers.
     Returns this job's aggregate numbers (all ranks) and rank-local quality figures."""
     import torch
@@ -201,7 +203,8 @@ def measure(args, info, sharding, cfg_id, steps, warmup, D, batch=0):
     # each rank owns its own shard of pairs, generated on its own device (no host staging, no exchange)
     t_gen = time.perf_counter()
     I1, I2, p_gt = eng.make_batch(sharding.shard_seed(cfg_id, info.rank), B, H, W, C, cfg["transform"],
-                                  robust_clutter=cfg["robust"] != 0)
+                                  robust_clutter=cfg["robust"] != 0,
+                                  dtype=torch.uint8 if storage == "u8" else torch.float32)
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t_gen
     prob = eng.problem(B, H, W, C, cfg["transform"], cfg["robust"], nscales=cfg["nscales"], nu=0.5, tol=1e-3,
@@ -339,7 +342,7 @@ def measure(args, info, sharding, cfg_id, steps, warmup, D, batch=0):
         mean_iters_per_scale=[acc["per_scale"][s] / float(B * steps) for s in range(ns)],
         roofline={
             "bound": "hbm",
-            "kernel": f"ica_accumulate2_kernel{kernel_key(cfg)} ({TNAME[cfg['transform']]}, "
+            "kernel": f"ica_iterate_kernel{kernel_key(cfg)} ({TNAME[cfg['transform']]}, "
                       f"{'robust: H+b every iteration' if cfg['robust'] else 'L2: b only, iterations >= 1'}), "
                       "all its launches of the event-bracketed steps at all scales (grids shrink as pairs converge)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -352,7 +355,13 @@ def measure(args, info, sharding, cfg_id, steps, warmup, D, batch=0):
                        "frac": (acc["s0_bytes"] / (acc["s0_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if acc["s0_ms"] > 0 else None,
                        "avg_launch_ms": acc["s0_ms"] / max(acc["s0_n"], 1), "launches": acc["s0_n"]},
             "first_iteration_kernel_share_of_step": acc["first_ms"] / max(n_prof, 1) / ms_per_step,
+            # `achieved` / `frac` use SURVEY 8(d)'s figure, 2*H*W*C*4 bytes per pair-iteration, whatever the storage.
+            # With uint8 level-0 images the bytes that exist in HBM at scale 0 are a quarter of that: frac_1B is the
+            # scale-0 launches priced at 1 byte per element.
             "bytes_per_element_convention": 4,
+            "storage": storage,
+            "scale0_frac_1B_convention": ((acc["s0_bytes"] / 4.0 / (acc["s0_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                                          if (storage == "u8" and acc["s0_ms"] > 0) else None),
         },
         quality={"converged_frac": converged, "hit_iteration_cap_frac": hit_cap,
                  "median_abs_param_err_vs_gt": float(perr.median()), "mean_iters_per_pair": units_all / pairs_all},
@@ -375,6 +384,8 @@ def main():
     ap.add_argument("--in-flight", type=int, default=IN_FLIGHT_DEFAULT,
                     help="solves kept in flight per GPU (one engine + HIP stream + host thread each): the straggler "
                          "launches of one solve overlap the pyramid and coarse levels of the next")
+    ap.add_argument("--storage", choices=("f32", "u8"), default="f32",
+                    help="element type of the level-0 images in HBM (uint8: SURVEY 8(f)3; same results, a quarter of the bytes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-per-config", action="store_true", help="skip the per_config side measurements (N = 1 only)")
     args = ap.parse_args()
@@ -415,29 +426,30 @@ def main():
         return
 
     D = max(1, args.in_flight)
-    m = measure(args, info, sharding, args.config, args.steps, args.warmup, D, args.batch)
+    m = measure(args, info, sharding, args.config, args.steps, args.warmup, D, args.batch, args.storage)
     cfg = m["cfg"]
 
     per_config = None
     if world == 1 and not args.no_per_config and not args.batch:
         per_config = []
-        for cid, steps in SIDE_CONFIGS:
-            if cid == args.config:
+        for cid, steps, stor in SIDE_CONFIGS:
+            if cid == args.config and stor == args.storage:
                 continue
             if time.perf_counter() - T_START > SIDE_DEADLINE_S:
                 per_config.append({"workload": CONFIGS[cid]["name"], "skipped": "time budget of the default run"})
                 continue
             try:
-                s = measure(args, info, sharding, cid, steps, 1, 1)
+                s = measure(args, info, sharding, cid, steps, 1, 1, storage=stor)
             except Exception as exc:  # a side measurement must never cost the headline line
                 per_config.append({"workload": CONFIGS[cid]["name"], "error": repr(exc)[:200]})
                 continue
-            per_config.append({"workload": s["cfg"]["name"], "value": s["units_all"] / s["dt"], "unit": "pair-iterations/s",
+            per_config.append({"workload": s["cfg"]["name"] + (" [uint8 level-0 images]" if stor == "u8" else ""),
+                               "storage": stor, "value": s["units_all"] / s["dt"], "unit": "pair-iterations/s",
                                "steps": steps, "warmup": 1, "ms_per_step": s["ms_per_step"],
                                "image_pairs_per_s": s["pairs_all"] / s["dt"],
                                "roofline": {k: s["roofline"][k] for k in ("kernel", "achieved", "frac", "avg_launch_ms",
                                                                           "launches", "traffic", "algorithmic_bytes_per_launch",
-                                                                          "scale0")},
+                                                                          "scale0", "scale0_frac_1B_convention")},
                                "converged_frac": s["quality"]["converged_frac"],
                                "hit_iteration_cap_frac": s["quality"]["hit_iteration_cap_frac"],
                                "mean_iters_per_pair": s["quality"]["mean_iters_per_pair"]})
@@ -454,11 +466,11 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32",   # the arithmetic type of the path (per pixel; sums and solve are f64), whatever the storage
             "data": "synthetic",
             "config": {"workload": cfg["name"], "pairs_per_gpu": cfg["batch"], "height": cfg["H"], "width": cfg["W"],
                        "channels": cfg["C"], "transform": TNAME[cfg["transform"]], "robust_type": cfg["robust"],
-                       "nscales": cfg["nscales"], "tol": 1e-3, "delta": 10,
+                       "nscales": cfg["nscales"], "tol": 1e-3, "delta": 10, "storage": args.storage,
                        "parallelism": f"{n_ranks} x independent pair shards (no collective)"
                        + (f", {D} solves in flight per GPU" if D > 1 else ""), "in_flight": D,
                        "note": "synthetic pairs: multi-octave noise texture, ground-truth transform of a few percent, "

@@ -12,7 +12,10 @@
  *
  * Conventions
  *   - plain C types only; no torch / HIP types appear in any signature (a stream is a void*).
- *   - images are float32, planar: [batch][channels][height][width], contiguous.
+ *   - images are planar: [batch][channels][height][width], contiguous; float32, or uint8 when
+ *     ica_problem.storage == ICA_STORAGE_U8 (the reference's data is 8-bit and it casts on entry, ref :63-65, :314-316:
+ *     such images stay one byte per pixel in HBM; the pyramid levels built from them are float32 either way, and the
+ *     two storages give bit-identical results on the same pixel values).
  *     (The reference holds (H,W,3) float64 arrays; the Python shim transposes and converts.)
  *   - transform parameters are float64, 8 per pair, zero padded: p[b*8 + k], k < nparams.
  *   - "_dev" functions take DEVICE pointers and enqueue on the context's stream without
@@ -60,6 +63,9 @@ typedef enum ica_robust {
   ICA_CHARBONNIER = 4
 } ica_robust;
 
+/* element type of the level-0 images handed to ica_solve_batch*_ / ica_op_normal_equations_dev */
+typedef enum ica_storage { ICA_STORAGE_F32 = 0, ICA_STORAGE_U8 = 1 } ica_storage;
+
 enum {
   /* compositional update: use the exact matrix composition instead of the reference's closed forms,
    * which differ in AFFINITY p[1] (transformation.py:106) and HOMOGRAPHY p[4] (:136).  Default (0)
@@ -79,7 +85,7 @@ typedef struct ica_problem {
   int32_t nanifoutside;   /* ref :85                                                                    */
   int32_t delta;          /* ref :85-93                                                                 */
   int32_t flags;          /* ICA_FLAG_*                                                                 */
-  int32_t reserved;
+  int32_t storage;        /* ica_storage of I1 / I2 (uint8: 1 or 3 channels); outputs are float32 regardless    */
   double tol;             /* TOL, must be < 0.01 (ref :59)                                              */
   double lambda;          /* robust threshold; <= 0 selects the schedule below (ref :223)              */
   double nu;              /* pyramid downsampling factor (config.ini nu)                                */
@@ -90,7 +96,7 @@ typedef struct ica_problem {
 
 /* Filled by ica_solve_batch*_ when stats != NULL (the call then synchronises).
  * The iteration work of a scale is split by the kernel that did it: `iter_*` is the steady-state kernel
- * (L2: ica_accumulate2_kernel<TT, b-only, C>, iterations >= 1; robust: <TT, weighted H+b, C>, every iteration), `first_*`
+ * (L2: ica_iterate_kernel<TT, b-only, C, ..>, iterations >= 1; robust: <TT, weighted H+b, C, rho, ..>, every iteration), `first_*`
  * is the L2 path's first iteration of a level, which also accumulates the Hessian (<TT, unweighted H+b, C>; zeros for
  * robust). */
 typedef struct ica_stats {
@@ -99,6 +105,7 @@ typedef struct ica_stats {
   int64_t iter_launches[ICA_MAX_SCALES];   /* launches of the steady-state iteration kernel per scale   */
   double iter_kernel_ms[ICA_MAX_SCALES];   /* HIP-event time of those launches (profiling on), else 0   */
   double iter_kernel_bytes[ICA_MAX_SCALES];/* algorithmic bytes they processed: 2*H_l*W_l*C*4 per unit  */
+                                           /* (the 4-byte convention of SURVEY 8(d), also for uint8 storage) */
   int32_t level_width[ICA_MAX_SCALES], level_height[ICA_MAX_SCALES];
   int64_t first_launches[ICA_MAX_SCALES];  /* same three figures for the L2 first-iteration launches    */
   double first_kernel_ms[ICA_MAX_SCALES];
@@ -128,7 +135,7 @@ int ica_prepare(ica_ctx* ctx, const ica_problem* prob);
  * Replaces pyramidal_inverse_compositional_algorithm() (ref :264-374) for a batch of pairs; with
  * nscales == 1 it is inverse_compositional_algorithm() (:17-133, robust_type == QUADRATIC) or
  * robust_inverse_compositional_algorithm() (:135-261).
- *   I1, I2     [B][C][H][W] float32
+ *   I1, I2     [B][C][H][W] float32, or uint8 when prob->storage == ICA_STORAGE_U8
  *   p_inout    [B][8] float64: initial parameters in, solution out.  As in the reference, the initial
  *              value is only used when nscales == 1 (ref :327,:337,:372: coarser levels start at 0
  *              and ps[0] is overwritten).
@@ -140,10 +147,10 @@ int ica_prepare(ica_ctx* ctx, const ica_problem* prob);
  *              (ref :125-129, :253-257): |dp|, p after the update, lambda after its decay
  *   stats      nullable HOST pointer
  */
-int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* prob, const float* I1, const float* I2,
+int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* prob, const void* I1, const void* I2,
                         double* p_inout, double* error_out, int32_t* niter_out, float* DI_out,
                         float* Iw_out, double* trace_out, ica_stats* stats);
-int ica_solve_batch(ica_ctx* ctx, const ica_problem* prob, const float* I1, const float* I2,
+int ica_solve_batch(ica_ctx* ctx, const ica_problem* prob, const void* I1, const void* I2,
                     double* p_inout, double* error_out, int32_t* niter_out, float* DI_out,
                     float* Iw_out, double* trace_out, ica_stats* stats);
 
@@ -167,9 +174,10 @@ int ica_op_minmax_dev(ica_ctx* ctx, int batch, int channels, int height, int wid
  *   H = sum rho' * DIJ^T DIJ  derivatives.py:73-107
  * with the gradient / NaN frame of ref :81-93, the Jacobian of derivatives.py:7-70, the steepest
  * descent images of image_optimisation.py:158-194 and rho' of image_optimisation.py:17-79 all
- * recomputed on the fly.  lambda_it is [B] (ignored for QUADRATIC).  H_out [B][8][8], b_out [B][8]. */
-int ica_op_normal_equations_dev(ica_ctx* ctx, const ica_problem* prob, const float* I1,
-                                const float* I2, const double* p, const double* lambda_it,
+ * recomputed on the fly.  lambda_it is [B] (ignored for QUADRATIC).  H_out [B][8][8], b_out [B][8].
+ * I1 / I2 are float32 or uint8 as prob->storage says. */
+int ica_op_normal_equations_dev(ica_ctx* ctx, const ica_problem* prob, const void* I1,
+                                const void* I2, const double* p, const double* lambda_it,
                                 double* H_out, double* b_out);
 
 /* derivatives.py:110-130 + image_optimisation.py:146-155 + transformation.py:35-141:

@@ -8,6 +8,7 @@ import os
 ICA_MAX_SCALES = 16
 ICA_TRACE_STRIDE = 10
 ICA_FLAG_EXACT_UPDATE = 1
+ICA_STORAGE_F32, ICA_STORAGE_U8 = 0, 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ICA_LIB", os.path.join(_HERE, "libica_hip.so"))  # ICA_LIB: experiment builds only
@@ -23,7 +24,7 @@ class Problem(C.Structure):
     _fields_ = [("batch", C.c_int32), ("height", C.c_int32), ("width", C.c_int32), ("channels", C.c_int32),
                 ("transform_type", C.c_int32), ("robust_type", C.c_int32), ("nscales", C.c_int32),
                 ("max_iter", C.c_int32), ("nanifoutside", C.c_int32), ("delta", C.c_int32), ("flags", C.c_int32),
-                ("reserved", C.c_int32), ("tol", C.c_double), ("lambda_", C.c_double), ("nu", C.c_double),
+                ("storage", C.c_int32), ("tol", C.c_double), ("lambda_", C.c_double), ("nu", C.c_double),
                 ("lambda0", C.c_double), ("lambdaN", C.c_double), ("lambda_ratio", C.c_double)]
 
 

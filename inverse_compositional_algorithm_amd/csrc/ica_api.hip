@@ -130,6 +130,9 @@ int validate(const ica_problem* pr) {
   if (pr->robust_type < ICA_QUADRATIC || pr->robust_type > ICA_CHARBONNIER) return ICA_EINVAL_ROBUST;
   if (pr->nscales < 1 || pr->nscales > ICA_MAX_SCALES) return ICA_EINVAL_ARG;
   if (pr->max_iter < 0 || pr->max_iter > 100000) return ICA_EINVAL_ARG;
+  if (pr->storage != ICA_STORAGE_F32 && pr->storage != ICA_STORAGE_U8) return ICA_EINVAL_ARG;
+  // uint8 images: gray or RGB (the LDS-staged kernel); the 2- and 4-channel direct-gather kernel is float32 only
+  if (pr->storage == ICA_STORAGE_U8 && pr->channels != 1 && pr->channels != 3) return ICA_EINVAL_SHAPE;
   return ICA_OK;
 }
 
@@ -228,11 +231,12 @@ int get_op(ica_ctx* ctx, int n_in, int n_out, DeviceBandOp** out) {
   return ICA_OK;
 }
 
-int launch_minmax(ica_ctx* ctx, int batch, size_t elems, const float* img, float* out) {
+template <class TIn>
+int launch_minmax(ica_ctx* ctx, int batch, size_t elems, const TIn* img, float* out) {
   int chunks = (int)std::min<size_t>(64, (elems + (size_t)kBlock * 16 - 1) / ((size_t)kBlock * 16));
   chunks = std::max(chunks, 1);
   ICA_HIP(ctx, ctx->mm_part.ensure((size_t)batch * chunks * 2 * sizeof(float)));
-  hipLaunchKernelGGL(ica_minmax_partial_kernel, dim3(chunks, batch), dim3(kBlock), 0, ctx->stream, img, elems, chunks,
+  hipLaunchKernelGGL(ica_minmax_partial_kernel<TIn>, dim3(chunks, batch), dim3(kBlock), 0, ctx->stream, img, elems, chunks,
                      ctx->mm_part.as<float>());
   hipLaunchKernelGGL(ica_minmax_final_kernel, dim3((batch + kWaves - 1) / kWaves), dim3(kBlock), 0, ctx->stream,
                      ctx->mm_part.as<float>(), chunks, batch, out);
@@ -242,7 +246,9 @@ int launch_minmax(ica_ctx* ctx, int batch, size_t elems, const float* img, float
 
 // One pyramid step.  `mm_out` ([batch][2]) receives the min/max of `in` (the clip range of skimage's rescale, and --
 // for I2 -- of the warp at that level); it is folded into the vertical pass, which reads every pixel of `in` anyway.
-int launch_pyramid_down(ica_ctx* ctx, int batch, int C, int H, int W, int h, int w, const float* in, float* out,
+// TIn: element type of `in` (uint8 for the level-0 images of an ICA_STORAGE_U8 problem); `out` is always float32.
+template <class TIn>
+int launch_pyramid_down(ica_ctx* ctx, int batch, int C, int H, int W, int h, int w, const TIn* in, float* out,
                         float* mm_out) {
   DeviceBandOp *ox = nullptr, *oy = nullptr;
   ICA_TRY(get_op(ctx, W, w, &ox));
@@ -252,8 +258,10 @@ int launch_pyramid_down(ica_ctx* ctx, int batch, int C, int H, int W, int h, int
   const bool generic_v = oy->vspan_max > kVWin, generic_h = lds > 64 * 1024;
   ICA_HIP(ctx, ctx->tmp_resample.ensure((size_t)planes * h * W * sizeof(float)));
   float* tmp = ctx->tmp_resample.as<float>();
-  // 16-byte loads per lane in the vertical pass when rows and base pointers are 16-byte aligned, else 4-byte ones
-  const bool vec4 = W % 4 == 0 && ((uintptr_t)in % 16) == 0;
+  // 4 columns per lane (one 16-byte load, or one dword of uint8 pixels) in the vertical pass when rows and base
+  // pointers are aligned for it, else one column per lane
+  const bool vec4 = W % 4 == 0 && ((uintptr_t)in % (4 * sizeof(TIn))) == 0;
+  constexpr bool kF32 = std::is_same<TIn, float>::value;
   const int vgroups = (h + kOutsV - 1) / kOutsV, xblocks = vec4 ? (W + 255) / 256 : (W + 63) / 64;
   const int per_pair = C * vgroups * xblocks;  // min/max partials per pair written by the vertical pass
   float* part = nullptr;
@@ -269,15 +277,18 @@ int launch_pyramid_down(ica_ctx* ctx, int batch, int C, int H, int W, int h, int
     const int np = std::min(step, planes - p0);
     const dim3 gv(xblocks, (vgroups + kWaves - 1) / kWaves, np);
     float* pp = part ? part + (size_t)p0 * vgroups * xblocks * 2 : nullptr;
-    if (generic_v)  // very small nu: window of 16 outputs wider than the tiled pass is sized for
-      hipLaunchKernelGGL(ica_resample_generic_kernel<true>, dim3((W + kBlock - 1) / kBlock, h, np), dim3(kBlock), 0,
-                         ctx->stream, in + (size_t)p0 * H * W, tmp + (size_t)p0 * h * W, C, W, oy->view(),
-                         (const float*)nullptr);
-    else if (vec4)
-      hipLaunchKernelGGL(ica_resample_v_kernel<4>, gv, dim3(kBlock), 0, ctx->stream, in + (size_t)p0 * H * W,
+    if (generic_v) {  // very small nu: window of 16 outputs wider than the tiled pass is sized for
+      if constexpr (kF32)
+        hipLaunchKernelGGL(ica_resample_generic_kernel<true>, dim3((W + kBlock - 1) / kBlock, h, np), dim3(kBlock), 0,
+                           ctx->stream, in + (size_t)p0 * H * W, tmp + (size_t)p0 * h * W, C, W, oy->view(),
+                           (const float*)nullptr);
+      else
+        return ICA_EINVAL_ARG;  // (rejected up front by validate_storage)
+    } else if (vec4)
+      hipLaunchKernelGGL((ica_resample_v_kernel<4, TIn>), gv, dim3(kBlock), 0, ctx->stream, in + (size_t)p0 * H * W,
                          tmp + (size_t)p0 * h * W, np, C, W, oy->view(), pp);
     else
-      hipLaunchKernelGGL(ica_resample_v_kernel<1>, gv, dim3(kBlock), 0, ctx->stream, in + (size_t)p0 * H * W,
+      hipLaunchKernelGGL((ica_resample_v_kernel<1, TIn>), gv, dim3(kBlock), 0, ctx->stream, in + (size_t)p0 * H * W,
                          tmp + (size_t)p0 * h * W, np, C, W, oy->view(), pp);
   }
   if (part)
@@ -306,7 +317,7 @@ template <int TT, int MODE>
 void launch_accumulate_c(int variant, int C, dim3 grid, hipStream_t st, const LevelArgs& a) {
   // 1 and 3 channels (gray / RGB, the reference's data) run the LDS-staged kernel; 2 and 4 channels (the reference's
   // robust entry point takes any channel count, ref :168-177) run the direct-gather kernel
-  if (variant == 1 || C == 2 || C == 4) {
+  if ((variant == 1 && !a.u8) || C == 2 || C == 4) {  // (the cross-check kernel reads float32 images only)
     switch (C) {
       case 1: hipLaunchKernelGGL((ica_accumulate_kernel<TT, MODE, 1>), grid, dim3(kBlock), 0, st, a); break;
       case 2: hipLaunchKernelGGL((ica_accumulate_kernel<TT, MODE, 2>), grid, dim3(kBlock), 0, st, a); break;
@@ -360,15 +371,16 @@ int wait_board(volatile int* slot, double timeout_s) {
   return v;
 }
 
-int launch_warp(ica_ctx* ctx, int batch, int C, int H, int W, int tt, const float* I2, const double* p,
-                const float* minmax, const float* I1, float* Iw, float* DI) {
+template <class TIn>
+int launch_warp(ica_ctx* ctx, int batch, int C, int H, int W, int tt, const TIn* I2, const double* p,
+                const float* minmax, const TIn* I1, float* Iw, float* DI) {
   for (int b0 = 0; b0 < batch; b0 += 32768) {
     const int nb = std::min(32768, batch - b0);
     const size_t off = (size_t)b0 * C * H * W;
     dim3 grid((W + 63) / 64, (H + kWaves - 1) / kWaves, nb);
 #define ICA_WARP_CASE(CC)                                                                                              \
   case CC:                                                                                                             \
-    hipLaunchKernelGGL(ica_warp_kernel<CC>, grid, dim3(kBlock), 0, ctx->stream, I2 + off, I1 ? I1 + off : nullptr, H, W, \
+    hipLaunchKernelGGL((ica_warp_kernel<CC, TIn>), grid, dim3(kBlock), 0, ctx->stream, I2 + off, I1 ? I1 + off : nullptr, H, W, \
                        tt, p + (size_t)b0 * 8, minmax + (size_t)b0 * 2, Iw ? Iw + off : nullptr,                       \
                        DI ? DI + off : nullptr);                                                                       \
     break;
@@ -523,9 +535,14 @@ int ica_prepare(ica_ctx* ctx, const ica_problem* pr) {
   return ensure_state(ctx, pr, g);
 }
 
-int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, const float* I2, double* p,
+int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const void* I1v, const void* I2v, double* p,
                         double* error_out, int32_t* niter_out, float* DI_out, float* Iw_out, double* trace_out,
                         ica_stats* stats) {
+  // level 0 is the caller's images, float32 or uint8 (ica_problem.storage); every coarser level is float32
+  const float* I1 = static_cast<const float*>(I1v);
+  const float* I2 = static_cast<const float*>(I2v);
+  const unsigned char* I1b = static_cast<const unsigned char*>(I1v);
+  const unsigned char* I2b = static_cast<const unsigned char*>(I2v);
   if (!ctx || !I1 || !I2 || !p || !error_out || !niter_out) return ICA_EINVAL_ARG;
   ICA_TRY(validate(pr));
   ICA_HIP(ctx, hipSetDevice(ctx->device));
@@ -536,6 +553,7 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
   const int B = pr->batch, C = pr->channels, tt = pr->transform_type, n = nparams_of(tt);
   const bool robust = pr->robust_type != ICA_QUADRATIC;
   const int ns = pr->nscales, max_iter = pr->max_iter;
+  const bool u8 = pr->storage == ICA_STORAGE_U8;
 
   // ---- pyramid (ref :331-337) ----
   const float* L1[ICA_MAX_SCALES];
@@ -548,14 +566,23 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
   ICA_HIP(ctx, ctx->mm_in.ensure((size_t)B * 2 * sizeof(float)));
   float* mm2 = ctx->minmax.as<float>();
   for (int s = 1; s < ns; ++s) {
-    ICA_TRY(launch_pyramid_down(ctx, B, C, g[s - 1].H, g[s - 1].W, g[s].H, g[s].W, L1[s - 1], ctx->pyr1[s].as<float>(),
-                                ctx->mm_in.as<float>()));
-    ICA_TRY(launch_pyramid_down(ctx, B, C, g[s - 1].H, g[s - 1].W, g[s].H, g[s].W, L2[s - 1], ctx->pyr2[s].as<float>(),
-                                mm2 + (size_t)(s - 1) * B * 2));
+    if (s == 1 && u8) {
+      ICA_TRY(launch_pyramid_down(ctx, B, C, g[0].H, g[0].W, g[1].H, g[1].W, I1b, ctx->pyr1[1].as<float>(),
+                                  ctx->mm_in.as<float>()));
+      ICA_TRY(launch_pyramid_down(ctx, B, C, g[0].H, g[0].W, g[1].H, g[1].W, I2b, ctx->pyr2[1].as<float>(), mm2));
+    } else {
+      ICA_TRY(launch_pyramid_down(ctx, B, C, g[s - 1].H, g[s - 1].W, g[s].H, g[s].W, L1[s - 1], ctx->pyr1[s].as<float>(),
+                                  ctx->mm_in.as<float>()));
+      ICA_TRY(launch_pyramid_down(ctx, B, C, g[s - 1].H, g[s - 1].W, g[s].H, g[s].W, L2[s - 1], ctx->pyr2[s].as<float>(),
+                                  mm2 + (size_t)(s - 1) * B * 2));
+    }
     L1[s] = ctx->pyr1[s].as<float>();
     L2[s] = ctx->pyr2[s].as<float>();
   }
-  ICA_TRY(launch_minmax(ctx, B, (size_t)C * g[ns - 1].H * g[ns - 1].W, L2[ns - 1], mm2 + (size_t)(ns - 1) * B * 2));
+  if (ns == 1 && u8)
+    ICA_TRY(launch_minmax(ctx, B, (size_t)C * g[0].H * g[0].W, I2b, mm2));
+  else
+    ICA_TRY(launch_minmax(ctx, B, (size_t)C * g[ns - 1].H * g[ns - 1].W, L2[ns - 1], mm2 + (size_t)(ns - 1) * B * 2));
   if (ctx->board_dirty) ICA_HIP(ctx, hipStreamSynchronize(st));  // nothing may post to the board while it is reset
   for (size_t i = 0; i < (size_t)ns * std::max(1, max_iter); ++i) ctx->board[i] = -1;
   ctx->board_dirty = true;
@@ -594,6 +621,7 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
 
     LevelArgs la{};
     la.I1 = L1[s]; la.I2 = L2[s]; la.H = g[s].H; la.W = g[s].W;
+    la.u8 = (s == 0 && u8) ? 1 : 0;
     la.tiles_x = g[s].tiles_x; la.tiles_y = g[s].tiles_y; la.tile_h = g[s].tile_h;
     la.delta = pr->delta; la.nanif = pr->nanifoutside; la.robust_type = pr->robust_type;
     la.p = p; la.lambda_it = ctx->lambda_it.as<double>(); la.minmax = mm2 + (size_t)s * B * 2;
@@ -675,8 +703,10 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
   if (DI_out || Iw_out) {
     // Iw / DI of the last executed iteration at scale 0 = warp under the parameters BEFORE the last
     // update (ref :111-114 then :123, returned at :133).  minmax still holds the scale-0 range.
-    ICA_TRY(launch_warp(ctx, B, C, g[0].H, g[0].W, tt, I2, ctx->p_prev.as<double>(), mm2, I1,
-                        Iw_out, DI_out));
+    if (u8)
+      ICA_TRY(launch_warp(ctx, B, C, g[0].H, g[0].W, tt, I2b, ctx->p_prev.as<double>(), mm2, I1b, Iw_out, DI_out));
+    else
+      ICA_TRY(launch_warp(ctx, B, C, g[0].H, g[0].W, tt, I2, ctx->p_prev.as<double>(), mm2, I1, Iw_out, DI_out));
   }
   ICA_HIP(ctx, hipGetLastError());
 
@@ -709,12 +739,13 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, co
   return ICA_OK;
 }
 
-int ica_solve_batch(ica_ctx* ctx, const ica_problem* pr, const float* I1, const float* I2, double* p, double* error_out,
+int ica_solve_batch(ica_ctx* ctx, const ica_problem* pr, const void* I1, const void* I2, double* p, double* error_out,
                     int32_t* niter_out, float* DI_out, float* Iw_out, double* trace_out, ica_stats* stats) {
   if (!ctx || !I1 || !I2 || !p || !error_out || !niter_out) return ICA_EINVAL_ARG;
   ICA_TRY(validate(pr));
   ICA_HIP(ctx, hipSetDevice(ctx->device));
   const size_t B = pr->batch, img = B * pr->channels * pr->height * pr->width;
+  const size_t es = pr->storage == ICA_STORAGE_U8 ? 1 : 4;  // bytes per input pixel
   const size_t tr = B * pr->nscales * pr->max_iter * ICA_TRACE_STRIDE;
   DevBuf d1, d2, dp, de, dn, dDI, dIw, dtr;
   auto cleanup = [&]() { d1.release(); d2.release(); dp.release(); de.release(); dn.release(); dDI.release(); dIw.release(); dtr.release(); };
@@ -725,18 +756,18 @@ int ica_solve_batch(ica_ctx* ctx, const ica_problem* pr, const float* I1, const 
       rc = e == hipErrorOutOfMemory ? ICA_ENOMEM : ICA_EHIP;
     }
   };
-  H(d1.ensure(img * 4), "alloc I1"); H(d2.ensure(img * 4), "alloc I2"); H(dp.ensure(B * 8 * 8), "alloc p");
+  H(d1.ensure(img * es), "alloc I1"); H(d2.ensure(img * es), "alloc I2"); H(dp.ensure(B * 8 * 8), "alloc p");
   H(de.ensure(B * 8), "alloc err"); H(dn.ensure(B * pr->nscales * 4), "alloc niter");
   if (DI_out) H(dDI.ensure(img * 4), "alloc DI");
   if (Iw_out) H(dIw.ensure(img * 4), "alloc Iw");
   if (trace_out) H(dtr.ensure(std::max<size_t>(tr, 1) * 8), "alloc trace");
   if (rc == ICA_OK) {
-    H(hipMemcpyAsync(d1.ptr, I1, img * 4, hipMemcpyHostToDevice, ctx->stream), "copy I1");
-    H(hipMemcpyAsync(d2.ptr, I2, img * 4, hipMemcpyHostToDevice, ctx->stream), "copy I2");
+    H(hipMemcpyAsync(d1.ptr, I1, img * es, hipMemcpyHostToDevice, ctx->stream), "copy I1");
+    H(hipMemcpyAsync(d2.ptr, I2, img * es, hipMemcpyHostToDevice, ctx->stream), "copy I2");
     H(hipMemcpyAsync(dp.ptr, p, B * 64, hipMemcpyHostToDevice, ctx->stream), "copy p");
   }
   if (rc == ICA_OK)
-    rc = ica_solve_batch_dev(ctx, pr, d1.as<float>(), d2.as<float>(), dp.as<double>(), de.as<double>(), dn.as<int32_t>(),
+    rc = ica_solve_batch_dev(ctx, pr, d1.ptr, d2.ptr, dp.as<double>(), de.as<double>(), dn.as<int32_t>(),
                              DI_out ? dDI.as<float>() : nullptr, Iw_out ? dIw.as<float>() : nullptr,
                              trace_out ? dtr.as<double>() : nullptr, stats);
   if (rc == ICA_OK) {
@@ -777,7 +808,7 @@ int ica_op_warp_dev(ica_ctx* ctx, int batch, int channels, int height, int width
   return launch_warp(ctx, batch, channels, height, width, tt, I2, p, minmax, I1, Iw_out, DI_out);
 }
 
-int ica_op_normal_equations_dev(ica_ctx* ctx, const ica_problem* pr, const float* I1, const float* I2, const double* p,
+int ica_op_normal_equations_dev(ica_ctx* ctx, const ica_problem* pr, const void* I1, const void* I2, const double* p,
                                 const double* lambda_it, double* H_out, double* b_out) {
   if (!ctx || !I1 || !I2 || !p || !H_out || !b_out) return ICA_EINVAL_ARG;
   ICA_TRY(validate(pr));
@@ -790,9 +821,12 @@ int ica_op_normal_equations_dev(ica_ctx* ctx, const ica_problem* pr, const float
   level_sizes(ctx, &one, g);
   ICA_TRY(ensure_state(ctx, &one, g));
   const int B = pr->batch, C = pr->channels, tt = pr->transform_type, n = nparams_of(tt);
-  ICA_TRY(launch_minmax(ctx, B, (size_t)C * g[0].H * g[0].W, I2, ctx->minmax.as<float>()));
+  const bool u8 = pr->storage == ICA_STORAGE_U8;
+  if (u8) ICA_TRY(launch_minmax(ctx, B, (size_t)C * g[0].H * g[0].W, static_cast<const unsigned char*>(I2), ctx->minmax.as<float>()));
+  else ICA_TRY(launch_minmax(ctx, B, (size_t)C * g[0].H * g[0].W, static_cast<const float*>(I2), ctx->minmax.as<float>()));
   LevelArgs la{};
-  la.I1 = I1; la.I2 = I2; la.H = g[0].H; la.W = g[0].W;
+  la.I1 = static_cast<const float*>(I1); la.I2 = static_cast<const float*>(I2); la.H = g[0].H; la.W = g[0].W;
+  la.u8 = u8 ? 1 : 0;
   la.tiles_x = g[0].tiles_x; la.tiles_y = g[0].tiles_y; la.tile_h = g[0].tile_h;
   la.delta = pr->delta; la.nanif = pr->nanifoutside; la.robust_type = pr->robust_type;
   la.p = p; la.lambda_it = lambda_it; la.minmax = ctx->minmax.as<float>();

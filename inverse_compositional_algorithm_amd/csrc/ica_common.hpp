@@ -27,8 +27,9 @@ enum Mode { kModeL2 = 0, kModeRobust = 1, kModeHessian = 2, kModeL2First = 3 };
 #endif
 
 struct LevelArgs {
-  const float* I1;
+  const float* I1;          // float32, or uint8 when `u8` (reinterpreted by the kernels)
   const float* I2;
+  int u8;                   // the images of this level are uint8 in HBM (level 0 of an ICA_STORAGE_U8 problem)
   int H, W;
   int tiles_x, tiles_y, tile_h;
   int delta, nanif;
@@ -190,8 +191,8 @@ constexpr float kNearInteger = 1.0f / 65536.0f;  // fp32 positions closer than t
 // outside the image -- the reference's NaN (bicubic_interpolation.py:199, cval=nan).  The result is
 // clipped to [lo, hi] as skimage.transform.warp(clip=True) does.  `p` / `tt`: the pair's parameters, for the float64
 // re-evaluation of a position that fp32 puts within kNearInteger of an integer (exact_axis).
-template <int C>
-__device__ __forceinline__ bool warp_sample(const float* __restrict__ img, int H, int W, int x, int y,
+template <int C, class TIn>
+__device__ __forceinline__ bool warp_sample(const TIn* __restrict__ img, int H, int W, int x, int y,
                                             float dx, float dy, float lo, float hi, float* out, const double* p, int tt) {
   const float flx = floorf(dx), fly = floorf(dy);
   float fx = dx - flx, fy = dy - fly;
@@ -211,15 +212,15 @@ __device__ __forceinline__ bool warp_sample(const float* __restrict__ img, int H
   keys_weights(fx, wx);
   keys_weights(fy, wy);
   const size_t plane = (size_t)H * W;
-  const float* base = img + (size_t)(y0 - 1) * W + (x0 - 1);
+  const TIn* base = img + (size_t)(y0 - 1) * W + (x0 - 1);
 #pragma unroll
   for (int c = 0; c < C; ++c) {
-    const float* q = base + c * plane;
+    const TIn* q = base + c * plane;
     float v = 0.0f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float* row = q + (size_t)r * W;
-      const float s = wx[0] * row[0] + wx[1] * row[1] + wx[2] * row[2] + wx[3] * row[3];
+      const TIn* row = q + (size_t)r * W;
+      const float s = wx[0] * (float)row[0] + wx[1] * (float)row[1] + wx[2] * (float)row[2] + wx[3] * (float)row[3];
       v = fmaf(wy[r], s, v);
     }
     out[c] = fminf(fmaxf(v, lo), hi);

@@ -116,6 +116,16 @@ __device__ __forceinline__ void glds4(const float* gsrc, float* lds_base) {
                                    (__attribute__((address_space(3))) void*)lds_base, 4, 0, 0);
 }
 
+// one LDS-DMA instruction: 4 (uint8 storage) or 16 (float32) bytes per lane from descriptor `rs` at byte offset `off`
+// to LDS `dst` + bytes * lane.  (The size operand of the builtin must be a literal.)
+#define ICA_LDS_DMA(U8, rs, dst, off)                                                                                 \
+  do {                                                                                                                \
+    if constexpr (U8)                                                                                                 \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst), 4, (int)(off), 0, 0, 0); \
+    else                                                                                                              \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst), 16, (int)(off), 0, 0, 0); \
+  } while (0)
+
 // A wave-uniform value the compiler would keep in an SGPR (a VALU operand read from an SGPR costs 1.5-2.4x the
 // issue time of the same instruction on a VGPR, see the header): pin it to a VGPR.
 __device__ __forceinline__ float in_vgpr(float v) {
@@ -169,9 +179,19 @@ __device__ __forceinline__ float rho_prime_t(float t2, float lam2) {
   else return 1.0f;
 }
 
-template <int TT, int MODE, int C, int RT>
+// U8: the level's images are uint8 in HBM (ICA_STORAGE_U8, level 0 only).  The copies then move BYTES into
+// a staging area of the LDS (a quarter of the traffic: same lane -> (row, 4-pixel group) map, 4 bytes per lane instead
+// of 16), and each chunk is expanded once, 4 pixels per thread and step (one ds_read_b32, four v_cvt_f32_ubyte, one
+// ds_write_b128), into the float tile the bands read -- the bands, the masks and every sum are the float path's, so
+// on the same (uint8-valued) images the two storages give bit-identical results.  Converting inside the tap loop
+// instead (4 taps per dword) would put ~20 more vector instructions on every pixel of a loop that is bound by
+// vector-instruction issue; expanding costs ~3 per pixel.  One float tile + one staging area per
+// workgroup: barrier, expand chunk k, barrier, start the copy of chunk k+1, compute chunk k.
+template <int TT, int MODE, int C, int RT, bool U8>
 // (second launch bound = waves per SIMD the register allocator must leave room for: what the LDS footprint allows)
 __global__ __launch_bounds__(kBlock, (C == 1 ? ICA_ITER_WAVES : 1)) void ica_iterate_kernel(LevelArgs a) {
+  using TIn = std::conditional_t<U8, unsigned char, float>;
+  constexpr int ES = (int)sizeof(TIn);    // bytes per image element in HBM
   constexpr int N = NP<TT>::n;
   constexpr int NT = N * (N + 1) / 2;
   constexpr bool kB = (MODE != kModeHessian);
@@ -180,14 +200,17 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? ICA_ITER_WAVES : 1)) void ica_ite
   constexpr bool kRobust = (MODE == kModeRobust);
   using ML = MomLayout<TT>;
   using TC = TileCfg<C>;
-  constexpr int CH = TC::ch, RW = TC::rw, P2 = TC::p2, R2 = TC::r2, P1 = TC::p1, R1 = TC::r1, NBUF = TC::nbuf;
+  constexpr int CH = TC::ch, RW = TC::rw, P2 = TC::p2, R2 = TC::r2, P1 = TC::p1, R1 = TC::r1;
+  constexpr int NBUF = U8 ? 1 : TC::nbuf;                 // float tiles
+  constexpr int kStageFloats = U8 ? TC::buf_floats / 4 : 0;  // uint8 staging area, in floats (4 pixels each)
+  static_assert(TC::buf_floats % 16 == 0 && (C * P2 * R2) % 4 == 0, "tile regions must be whole 16-byte groups");
   constexpr int NMOM = ML::nmom;
   constexpr unsigned kPitchBits = P2 == 80 ? 0x43a00000u : P2 == 96 ? 0x43c00000u : 0u;  // (float)(P2 * 4)
   static_assert(kPitchBits != 0, "add the bit pattern of (float)(P2 * 4)");
 
   // The ring buffers; the end-of-tile fold reuses the same LDS.  The fold works on the moments in two halves when a
   // single pass would need more LDS than the ring (robust homography), so that it never costs an occupancy step.
-  constexpr int kRingFloats = NBUF * TC::buf_floats;
+  constexpr int kRingFloats = NBUF * TC::buf_floats + kStageFloats;
   constexpr int kFoldAll = 2 * (NMOM + N + NT) * 64;
   constexpr int kLdsFloats = kRingFloats > 2 * (NMOM + (N + NT + 1) / 2) * 64 ? kRingFloats : 2 * (NMOM + (N + NT + 1) / 2) * 64;
   constexpr bool kFoldSplit = kFoldAll > kLdsFloats;
@@ -220,8 +243,8 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? ICA_ITER_WAVES : 1)) void ica_ite
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int H = a.H, W = a.W;
   const size_t plane = (size_t)H * W;
-  const float* I1 = a.I1 + (size_t)pair * C * plane;
-  const float* I2 = a.I2 + (size_t)pair * C * plane;
+  const TIn* I1 = reinterpret_cast<const TIn*>(a.I1) + (size_t)pair * C * plane;
+  const TIn* I2 = reinterpret_cast<const TIn*>(a.I2) + (size_t)pair * C * plane;
 
   float A[8];
   float lo = 0.f, hi = 0.f, lam2 = 0.f;
@@ -257,7 +280,7 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? ICA_ITER_WAVES : 1)) void ica_ite
   const int xm1 = x - 1;
   const unsigned ux_max = (unsigned)(W - 4), uy_max = (unsigned)(H - 4);
   const bool can_sample = (W >= 4) & (H >= 4);  // else the unsigned range tests below would wrap
-  const bool w4 = (W & 3) == 0;                         // rows are 16-byte aligned -> 16-B LDS-DMA
+  const bool w4 = (W & 3) == 0;                         // rows start on 4-pixel boundaries -> whole-group LDS-DMA
 
   // ---- plan: lane c (< 32) computes the I2 footprint of chunk c: x_lo | flags (bit 30 = stage through LDS, bit 29 =
   //      skip, bit 28 = interior: no frame / border / invalid pixel in the chunk), which stays in lane c, and
@@ -323,7 +346,7 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? ICA_ITER_WAVES : 1)) void ica_ite
   // carries float4 number (l % V) of row (l / V) of the group, V = float4 per tile row, so the only per-lane state is
   // ONE byte offset per image (off1, off2), which does not depend on the chunk; everything else about a copy (first
   // row, row shift, how many rows) is wave-uniform.  The tile's row groups are dealt round-robin to the 4 waves.
-  const auto rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)I1, 0, (int)(C * plane * sizeof(float)), 0x00020000);
+  const auto rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)I1, 0, (int)(C * plane * ES), 0x00020000);
   constexpr int V1 = P1 / 4, V2 = P2 / 4;                       // float4 per buffer row
   constexpr int RP1 = 64 / V1, RP2 = 64 / V2;                   // rows per wave-instruction
   constexpr int NQ1 = (R1 + RP1 - 1) / RP1, NQ2 = (R2 + RP2 - 1) / RP2;  // row groups per tile
@@ -332,8 +355,8 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? ICA_ITER_WAVES : 1)) void ica_ite
   {
     const int r1 = lane / V1, c1 = lane - r1 * V1, r2 = lane / V2, c2 = lane - r2 * V2;
     const int xx = x_t0 - 4 + 4 * c1;
-    off1 = (xx >= 0 && xx < W) ? (unsigned)((r1 * W + 4 * c1 - 4) * 4) : kPoison;
-    off2 = (unsigned)((r2 * W + 4 * c2) * 4);
+    off1 = (xx >= 0 && xx < W) ? (unsigned)((r1 * W + 4 * c1 - 4) * ES) : kPoison;
+    off2 = (unsigned)((r2 * W + 4 * c2) * ES);
   }
 
   // issue the LDS-DMA copies of chunk k into buffer `buf` (no waits here).
@@ -345,14 +368,15 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? ICA_ITER_WAVES : 1)) void ica_ite
     return;  // timing-only build: no LDS-DMA
 #endif
     const int px = plan_px(k), y_lo = plan_ylo(k);
-    float* b2 = lds + buf * TC::buf_floats;
-    float* b1 = b2 + C * P2 * R2;
+    // destination: the float tile `buf`, or (U8) the staging area behind the tile, laid out like the tile, in bytes
+    TIn* b2 = U8 ? reinterpret_cast<TIn*>(lds + NBUF * TC::buf_floats) : reinterpret_cast<TIn*>(lds + buf * TC::buf_floats);
+    TIn* b1 = b2 + C * P2 * R2;
     const int yc0 = y_begin + k * CH;
     if (w4) {
       // a skipped (all-frame) chunk still issues its copies, with every lane out of range (the tile is zero-filled)
       const bool skip = (px & (1 << 29)) != 0;
       // may wrap below 0 (row -1): then out of range.  A skipped chunk gets an out-of-range base.
-      const unsigned base1 = skip ? 0x40000000u : (unsigned)(((yc0 - 1) * W + x_t0) * 4);
+      const unsigned base1 = skip ? 0x40000000u : (unsigned)(((yc0 - 1) * W + x_t0) * ES);
 #pragma unroll
       for (int qq = 0; qq < (NQ1 + kWaves - 1) / kWaves; ++qq) {
         const int q = wave + qq * kWaves;      // this wave's row group (wave-uniform)
@@ -360,14 +384,13 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? ICA_ITER_WAVES : 1)) void ica_ite
         // to LDS, which would land in the neighbouring tile.
         const int rows = min(RP1, R1 - RP1 * q);
         if (q < NQ1 && lane < V1 * rows) {
-          float* dst = b1 + RP1 * q * P1;
-          unsigned u = base1 + (unsigned)(RP1 * q * W * 4);
+          TIn* dst = b1 + RP1 * q * P1;
+          unsigned u = base1 + (unsigned)(RP1 * q * W * ES);
           asm volatile("" : "+s"(u));  // (opaque: the sum with off1 is formed here, not hoisted out of the chunk loop into a register)
           const unsigned o = off1 + u;  // a poisoned offset stays out of range
 #pragma unroll
           for (int c = 0; c < C; ++c)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (__attribute__((address_space(3))) void*)(dst + c * P1 * R1), 16,
-                                                     (int)(o + (unsigned)(c * plane * 4)), 0, 0, 0);
+            ICA_LDS_DMA(U8, rs1, dst + c * P1 * R1, o + (unsigned)(c * plane * ES));
         }
       }
       if constexpr (kB) {
@@ -377,25 +400,24 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? ICA_ITER_WAVES : 1)) void ica_ite
         // rows beyond the footprint fall outside this descriptor (a chunk that is not staged gets 0 rows) and are
         // zero-filled
         const auto rs2 = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)I2, 0, bh ? (int)(((size_t)(C - 1) * plane + (size_t)(y_lo + bh) * W) * 4) : 0, 0x00020000);
-        const unsigned base2 = (unsigned)((y_lo * W + x_lo) * 4);
+            (void*)I2, 0, bh ? (int)(((size_t)(C - 1) * plane + (size_t)(y_lo + bh) * W) * ES) : 0, 0x00020000);
+        const unsigned base2 = (unsigned)((y_lo * W + x_lo) * ES);
 #pragma unroll
         for (int qq = 0; qq < (NQ2 + kWaves - 1) / kWaves; ++qq) {
           const int q = wave + qq * kWaves;
           const int rows = min(RP2, R2 - RP2 * q);
           if (q < NQ2 && lane < V2 * rows) {
-            float* dst = b2 + RP2 * q * P2;
-            unsigned u = base2 + (unsigned)(RP2 * q * W * 4);
+            TIn* dst = b2 + RP2 * q * P2;
+            unsigned u = base2 + (unsigned)(RP2 * q * W * ES);
             asm volatile("" : "+s"(u));
             const unsigned o = off2 + u;  // all P2 columns of a row are copied (a few more than needed)
 #pragma unroll
             for (int c = 0; c < C; ++c)
-              __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (__attribute__((address_space(3))) void*)(dst + c * P2 * R2), 16,
-                                                       (int)(o + (unsigned)(c * plane * 4)), 0, 0, 0);
+              ICA_LDS_DMA(U8, rs2, dst + c * P2 * R2, o + (unsigned)(c * plane * ES));
           }
         }
       }
-    } else {
+    } else if constexpr (!U8) {
       if (px & (1 << 29)) return;
       for (int r = wave; r < R1; r += kWaves) {
         const int yy = yc0 - 1 + r;
@@ -445,10 +467,44 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? ICA_ITER_WAVES : 1)) void ica_ite
   // makes every wave's part visible, and also means everyone has finished reading chunk k-1, whose buffer is the one
   // chunk k+1 is about to overwrite.
   static_assert(NBUF == 1 || NBUF == 2, "one or two staging buffers");
-  if (NBUF == 2) issue(0, 0);
+  // U8: staging area -> float tile, 4 pixels per thread and step; rows whose width is not a multiple of 4 pixels (no
+  // whole-group copies) are read straight from memory, element by element (cold path: odd widths at level 0)
+  [[maybe_unused]] auto expand = [&](int k) {
+    if (w4) {
+      const unsigned* s32 = reinterpret_cast<const unsigned*>(lds + TC::buf_floats);
+      for (int e = threadIdx.x; e < TC::buf_floats / 4; e += kBlock) {
+        const unsigned u = s32[e];
+        float4 v;
+        v.x = (float)(u & 0xffu); v.y = (float)((u >> 8) & 0xffu); v.z = (float)((u >> 16) & 0xffu); v.w = (float)(u >> 24);
+        *reinterpret_cast<float4*>(lds + 4 * e) = v;
+      }
+    } else {
+      const int px = plan_px(k), y_lo = plan_ylo(k), x_lo = px & 0xFFFFF, yc0 = y_begin + k * CH;
+      for (int e = threadIdx.x; e < TC::buf_floats; e += kBlock) {
+        const bool two = e < C * P2 * R2;                  // I2 footprint region, else I1 tile region
+        const int f = two ? e : e - C * P2 * R2, pitch = two ? P2 : P1, rows = two ? R2 : R1;
+        const int c = f / (pitch * rows), g = f - c * pitch * rows, r = g / pitch, col = g - r * pitch;
+        const int yy = two ? y_lo + r : yc0 - 1 + r, xx = two ? x_lo + col : x_t0 - 4 + col;
+        const TIn* img = two ? I2 : I1;
+        const bool in = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W) & (two ? (kB && (px & (1 << 30)) != 0) : true);
+        lds[e] = in ? (float)img[c * plane + (size_t)yy * W + xx] : 0.0f;
+      }
+    }
+  };
+  if (U8) {
+    if (w4) issue(0, 0);
+  } else if (NBUF == 2) {
+    issue(0, 0);
+  }
   for (int k = 0; k < nchunks; ++k) {
     const int buf = (NBUF >= 2) ? (k % NBUF) : 0;
-    if (NBUF == 1) {
+    if constexpr (U8) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();   // chunk k's bytes are in the staging area; everyone is done with the float tile
+      expand(k);
+      __syncthreads();                // the float tile holds chunk k; the staging area is free
+      if (w4 && k + 1 < nchunks) issue(k + 1, 0);
+    } else if (NBUF == 1) {
       __syncthreads();  // everyone is done reading the single buffer
       issue(k, 0);
       __syncthreads();  // drains this wave's LDS-DMA (vmcnt(0)) and publishes chunk k
@@ -676,19 +732,19 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? ICA_ITER_WAVES : 1)) void ica_ite
               iw[c] = v;
             }
           } else {
-            const float* t = I2 + (valid ? (size_t)uy * W + ux : 0);
+            const TIn* t = I2 + (valid ? (size_t)uy * W + ux : 0);
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-              const float* q = t + c * plane;
+              const TIn* q = t + c * plane;
               float v = 0.f;
               if (valid) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                  const float* rp = q + (size_t)r * W;
-                  float s = wx[0] * rp[0];
-                  s = __builtin_fmaf(wx[1], rp[1], s);
-                  s = __builtin_fmaf(wx[2], rp[2], s);
-                  s = __builtin_fmaf(wx[3], rp[3], s);
+                  const TIn* rp = q + (size_t)r * W;
+                  float s = wx[0] * (float)rp[0];
+                  s = __builtin_fmaf(wx[1], (float)rp[1], s);
+                  s = __builtin_fmaf(wx[2], (float)rp[2], s);
+                  s = __builtin_fmaf(wx[3], (float)rp[3], s);
                   v = (r == 0) ? wy[0] * s : __builtin_fmaf(wy[r], s, v);
                 }
               }

@@ -1,5 +1,5 @@
-// Instantiations of the fused iteration kernel for ONE transform type (-DICA_INST_TT=1..5): 2 channel counts x
-// (L2, L2-first, Hessian + 4 robust error functions).  build.py compiles this file five times, in parallel.
+// Instantiations of the fused iteration kernel for ONE transform type (-DICA_INST_TT=1..5): 2 channel counts x 2 image
+// storages (float32, uint8) x (L2, L2-first, Hessian + 4 robust error functions).  build.py compiles this file five times, in parallel.
 #include "ica_iterate.hpp"
 #include "ica_iterate_launch.hpp"
 
@@ -12,8 +12,13 @@ namespace {
 
 template <int TT, int MODE, int RT>
 void launch_c(int channels, unsigned blocks, hipStream_t st, const LevelArgs& a) {
-  if (channels == 1) hipLaunchKernelGGL((ica_iterate_kernel<TT, MODE, 1, RT>), dim3(blocks), dim3(kBlock), 0, st, a);
-  else hipLaunchKernelGGL((ica_iterate_kernel<TT, MODE, 3, RT>), dim3(blocks), dim3(kBlock), 0, st, a);
+  if (a.u8) {  // this level's images are uint8 in HBM (level 0 of an ICA_STORAGE_U8 problem)
+    if (channels == 1) hipLaunchKernelGGL((ica_iterate_kernel<TT, MODE, 1, RT, true>), dim3(blocks), dim3(kBlock), 0, st, a);
+    else hipLaunchKernelGGL((ica_iterate_kernel<TT, MODE, 3, RT, true>), dim3(blocks), dim3(kBlock), 0, st, a);
+  } else {
+    if (channels == 1) hipLaunchKernelGGL((ica_iterate_kernel<TT, MODE, 1, RT, false>), dim3(blocks), dim3(kBlock), 0, st, a);
+    else hipLaunchKernelGGL((ica_iterate_kernel<TT, MODE, 3, RT, false>), dim3(blocks), dim3(kBlock), 0, st, a);
+  }
 }
 
 template <int TT>

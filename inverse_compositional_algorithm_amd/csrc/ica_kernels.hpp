@@ -78,7 +78,7 @@ __global__ __launch_bounds__(kBlock) void ica_accumulate_kernel(LevelArgs a) {
         float iw[C];
         if constexpr (kB) {
           displacement<kProj>(A, xf, yf, dxw, dyw);
-          valid = warp_sample<C>(I2, H, W, x, y, dxw, dyw, lo, hi, iw, a.p + (size_t)pair * 8, TT);
+          valid = warp_sample<C, float>(I2, H, W, x, y, dxw, dyw, lo, hi, iw, a.p + (size_t)pair * 8, TT);
         }
         const float* c1 = I1 + (size_t)y * W + x;
 #pragma unroll
@@ -440,8 +440,8 @@ __global__ void ica_finish_kernel(int batch, int nscales, const int* niter, cons
 }
 
 // ---- warp operator (Iw / DI write-out, data generation) -------------------------------------------
-template <int C>
-__global__ __launch_bounds__(kBlock) void ica_warp_kernel(const float* __restrict__ I2, const float* __restrict__ I1,
+template <int C, class TIn>
+__global__ __launch_bounds__(kBlock) void ica_warp_kernel(const TIn* __restrict__ I2, const TIn* __restrict__ I1,
                                                           int H, int W, int tt, const double* __restrict__ p,
                                                           const float* __restrict__ minmax, float* __restrict__ Iw,
                                                           float* __restrict__ DI) {
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(kBlock) void ica_warp_kernel(const float* __restric
   const size_t plane = (size_t)H * W;
   const size_t base = (size_t)pair * C * plane;
   float v[C];
-  const bool ok = warp_sample<C>(I2 + base, H, W, x, y, dx, dy, minmax[pair * 2], minmax[pair * 2 + 1], v,
+  const bool ok = warp_sample<C, TIn>(I2 + base, H, W, x, y, dx, dy, minmax[pair * 2], minmax[pair * 2 + 1], v,
                                  p + (size_t)pair * 8, tt);
   const float nanv = __builtin_nanf("");
 #pragma unroll
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(kBlock) void ica_warp_kernel(const float* __restric
     const size_t o = base + c * plane + (size_t)y * W + x;
     const float iw = ok ? v[c] : nanv;
     if (Iw) Iw[o] = iw;
-    if (DI) DI[o] = iw - I1[o];
+    if (DI) DI[o] = iw - (float)I1[o];
   }
 }
 
@@ -504,15 +504,16 @@ __global__ __launch_bounds__(kBlock) void ica_transform_image_kernel(const float
 }
 
 // ---- min / max of each image ----------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void ica_minmax_partial_kernel(const float* __restrict__ img, size_t elems,
+template <class TIn>
+__global__ __launch_bounds__(kBlock) void ica_minmax_partial_kernel(const TIn* __restrict__ img, size_t elems,
                                                                     int chunks, float* __restrict__ part) {
   const int pair = blockIdx.y, chunk = blockIdx.x;
-  const float* q = img + (size_t)pair * elems;
+  const TIn* q = img + (size_t)pair * elems;
   const size_t per = (elems + chunks - 1) / chunks;
   const size_t beg = (size_t)chunk * per, end = min(elems, beg + per);
   float lo = INFINITY, hi = -INFINITY;
   for (size_t i = beg + threadIdx.x; i < end; i += kBlock) {
-    const float v = q[i];
+    const float v = (float)q[i];
     lo = fminf(lo, v);
     hi = fmaxf(hi, v);
   }
@@ -622,8 +623,9 @@ constexpr int kRowsH = 32;   // rows per workgroup in the horizontal pass (8 per
 // only sees v_fmac / v_pk_fma(acc, sgpr, value).
 // The operator weights are float64 on the host (ica_pyramid.hpp); they are applied in fp32 like every other
 // per-pixel quantity of the engine (the result is stored as fp32 anyway).
-template <int VEC>
-__global__ __launch_bounds__(kBlock) void ica_resample_v_kernel(const float* __restrict__ in, float* __restrict__ out,
+// TIn = unsigned char: the input is a uint8 level-0 image (4 columns per lane = one dword load); converted on load.
+template <int VEC, class TIn>
+__global__ __launch_bounds__(kBlock) void ica_resample_v_kernel(const TIn* __restrict__ in, float* __restrict__ out,
                                                                 int planes, int channels, int W, BandOp op,
                                                                 float* __restrict__ mm_part) {
   typedef float vecf __attribute__((ext_vector_type(VEC)));
@@ -644,7 +646,7 @@ __global__ __launch_bounds__(kBlock) void ica_resample_v_kernel(const float* __r
 #pragma unroll
     for (int v = 0; v < VEC; ++v) acc[i][v] = 0.f;
   const bool xin = x < W;
-  const float* col = in + (size_t)pl * op.n_in * W + (size_t)j0 * W + (xin ? x : 0);
+  const TIn* col = in + (size_t)pl * op.n_in * W + (size_t)j0 * W + (xin ? x : 0);
   float lo = INFINITY, hi = -INFINITY;
   auto run = [&](int a, int b, auto track_c) {  // rows [a, b) of the window; track_c: fold them into min/max
     constexpr bool TRACK = decltype(track_c)::value;
@@ -652,11 +654,15 @@ __global__ __launch_bounds__(kBlock) void ica_resample_v_kernel(const float* __r
     for (int jj = a; jj < b; ++jj) {
       float val[VEC];
       if constexpr (VEC == 1) {
-        val[0] = col[(size_t)jj * W];
-      } else {
+        val[0] = (float)col[(size_t)jj * W];
+      } else if constexpr (std::is_same_v<TIn, float>) {
         const vecf t = *reinterpret_cast<const vecf*>(col + (size_t)jj * W);
 #pragma unroll
         for (int v = 0; v < VEC; ++v) val[v] = t[v];
+      } else {
+        static_assert(VEC == 4, "uint8 rows are read 4 pixels (one dword) per lane");
+        const unsigned t = *reinterpret_cast<const unsigned*>(col + (size_t)jj * W);
+        val[0] = (float)(t & 0xffu); val[1] = (float)((t >> 8) & 0xffu); val[2] = (float)((t >> 16) & 0xffu); val[3] = (float)(t >> 24);
       }
       if constexpr (TRACK) {
 #pragma unroll

@@ -1,7 +1,8 @@
 """Batched device-side engine: thin Python host code over the C ABI (include/ica_hip.h).
 
 PyTorch is used for device memory and streams only; every computation happens in libica_hip.so.
-Images are float32 planar ``[B, C, H, W]`` CUDA(HIP) tensors; parameters are float64 ``[B, 8]``.
+Images are planar ``[B, C, H, W]`` CUDA(HIP) tensors, float32 or uint8 (8-bit images stay one byte per pixel in HBM;
+the two storages give bit-identical results on the same pixel values); parameters are float64 ``[B, 8]``.
 """
 from __future__ import annotations
 
@@ -71,18 +72,27 @@ class IcaEngine:
 
     @staticmethod
     def problem(batch, height, width, channels, transform_type, robust_type=0, nscales=1, nu=0.5, tol=1e-3,
-                lambda_=0.0, nanifoutside=True, delta=10, max_iter=MAX_ITER, flags=0) -> Problem:
+                lambda_=0.0, nanifoutside=True, delta=10, max_iter=MAX_ITER, flags=0, storage=0) -> Problem:
+        """`storage`: _lib.ICA_STORAGE_F32 / ICA_STORAGE_U8; solve() and normal_equations() set it from the tensors' dtype."""
         return Problem(batch=batch, height=height, width=width, channels=channels, transform_type=int(transform_type),
                        robust_type=int(robust_type), nscales=nscales, max_iter=max_iter,
-                       nanifoutside=int(bool(nanifoutside)), delta=int(delta), flags=flags, reserved=0, tol=tol,
+                       nanifoutside=int(bool(nanifoutside)), delta=int(delta), flags=flags, storage=int(storage), tol=tol,
                        lambda_=lambda_, nu=nu, lambda0=LAMBDA_0, lambdaN=LAMBDA_N, lambda_ratio=LAMBDA_RATIO)
 
-    def _images(self, *ts):
+    def _images(self, *ts, allow_u8=False):
+        """Returns the storage code of the images (all of one dtype)."""
+        dts = set()
         for t in ts:
             if t is None:
                 continue
-            if t.dtype != torch.float32 or t.dim() != 4 or not t.is_contiguous() or t.device != self.device:
-                raise ValueError("images must be contiguous float32 [B, C, H, W] tensors on the engine's device")
+            ok = t.dtype == torch.float32 or (allow_u8 and t.dtype == torch.uint8)
+            if not ok or t.dim() != 4 or not t.is_contiguous() or t.device != self.device:
+                raise ValueError("images must be contiguous float32%s [B, C, H, W] tensors on the engine's device"
+                                 % (" or uint8" if allow_u8 else ""))
+            dts.add(t.dtype)
+        if len(dts) > 1:
+            raise ValueError("I1 and I2 must have the same dtype")
+        return _lib.ICA_STORAGE_U8 if torch.uint8 in dts else _lib.ICA_STORAGE_F32
 
     def prepare(self, prob: Problem):
         check(self.lib.ica_prepare(self.ctx, C.byref(prob)), self.ctx)
@@ -90,7 +100,7 @@ class IcaEngine:
     # -- the hot path ----------------------------------------------------------------------------
     def solve(self, I1: torch.Tensor, I2: torch.Tensor, prob: Problem, p0: Optional[torch.Tensor] = None,
               want_images: bool = False, want_trace: bool = False, want_stats: bool = False) -> SolveResult:
-        self._images(I1, I2)
+        prob.storage = self._images(I1, I2, allow_u8=True)
         if I1.shape != I2.shape:
             check(-2)
         B, Cc, H, W = I1.shape
@@ -103,8 +113,8 @@ class IcaEngine:
             p[:, :p0.shape[1]] = p0
         err = torch.empty(B, dtype=torch.float64, device=dev)
         nit = torch.empty(B, prob.nscales, dtype=torch.int32, device=dev)
-        DI = torch.empty_like(I1) if want_images else None
-        Iw = torch.empty_like(I1) if want_images else None
+        DI = torch.empty(I1.shape, dtype=torch.float32, device=dev) if want_images else None
+        Iw = torch.empty(I1.shape, dtype=torch.float32, device=dev) if want_images else None
         tr = (torch.empty(B, prob.nscales, prob.max_iter, _lib.ICA_TRACE_STRIDE, dtype=torch.float64, device=dev)
               if want_trace else None)
         st = Stats() if want_stats else None
@@ -150,7 +160,7 @@ class IcaEngine:
 
     def normal_equations(self, I1, I2, p, prob: Problem, lambda_it=None):
         """H [B,8,8], b [B,8] of one iteration at parameters p."""
-        self._images(I1, I2)
+        prob.storage = self._images(I1, I2, allow_u8=True)
         B = I1.shape[0]
         p = self._params(p, B)
         lam = None
@@ -214,16 +224,17 @@ class IcaEngine:
 
     # -- synthetic workloads on the device (same distribution as synthetic.make_pair) --------------
     def make_batch(self, seed: int, batch: int, height: int, width: int, channels: int, transform_type: int,
-                   robust_clutter: bool = False, chunk: int = 64):
+                   robust_clutter: bool = False, chunk: int = 64, dtype=torch.float32):
         """Bulk synthetic warped pairs generated on the GPU: multi-octave noise texture I2, random small
         ground-truth transform, I1 = round_u8(bicubic I2(M(p_gt) x)) through this library's own warp
-        operator.  Returns (I1, I2, p_gt[B, 8])."""
+        operator.  Returns (I1, I2, p_gt[B, 8]); pixel values are integers 0..255 either way, `dtype`
+        (torch.float32 / torch.uint8) is how they are stored."""
         from . import synthetic as syn
         dev = self.device
         g = torch.Generator(device=dev)
         g.manual_seed(seed)
         rng = np.random.default_rng(seed)
-        I1 = torch.empty(batch, channels, height, width, dtype=torch.float32, device=dev)
+        I1 = torch.empty(batch, channels, height, width, dtype=dtype, device=dev)
         I2 = torch.empty_like(I1)
         n = syn.NPARAMS[int(transform_type)]
         pg = np.zeros((batch, 8))
@@ -248,8 +259,9 @@ class IcaEngine:
             acc = acc.view(nb, channels, height, width)
             lo = acc.amin(dim=(1, 2, 3), keepdim=True)
             hi = acc.amax(dim=(1, 2, 3), keepdim=True)
-            I2[b0:b0 + nb] = torch.round((acc - lo) / (hi - lo) * 255.0)
-            iw = self.warp(I2[b0:b0 + nb].contiguous(), p_gt[b0:b0 + nb], transform_type)
+            i2 = torch.round((acc - lo) / (hi - lo) * 255.0)
+            I2[b0:b0 + nb] = i2.to(dtype)
+            iw = self.warp(i2.contiguous(), p_gt[b0:b0 + nb], transform_type)
             iw = torch.nan_to_num(iw, nan=0.0)
             if robust_clutter:
                 iw = iw + 5.0 * torch.randn(iw.shape, device=dev, generator=g)
@@ -259,5 +271,5 @@ class IcaEngine:
                     ox = int(rng.integers(0, width - ow))
                     iw[i, :, oy:oy + oh, ox:ox + ow] = torch.randint(0, 256, (channels, oh, ow), device=dev,
                                                                      generator=g).float()
-            I1[b0:b0 + nb] = torch.clamp(torch.round(iw), 0, 255)
+            I1[b0:b0 + nb] = torch.clamp(torch.round(iw), 0, 255).to(dtype)
         return I1, I2, p_gt

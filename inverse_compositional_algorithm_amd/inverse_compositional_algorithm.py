@@ -26,8 +26,10 @@ def _engine(device: int = 0) -> IcaEngine:
     return _ENGINES[device]
 
 
-def _to_device(img: np.ndarray, eng: IcaEngine) -> torch.Tensor:
-    a = np.ascontiguousarray(np.moveaxis(np.asarray(img, dtype=np.float32), 2, 0))[None]
+def _to_device(img: np.ndarray, eng: IcaEngine, u8: bool = False) -> torch.Tensor:
+    """(H, W, C) -> [1, C, H, W] on the GPU.  8-bit images (the reference's whole data set; it casts them to float64 on
+    entry, ref :63-65, :314-316) travel and stay as uint8 -- same values, a quarter of the bytes."""
+    a = np.ascontiguousarray(np.moveaxis(np.asarray(img, dtype=np.uint8 if u8 else np.float32), 2, 0))[None]
     return torch.from_numpy(a).to(eng.device)
 
 
@@ -72,7 +74,9 @@ def _run(I1, I2, p, transform_type, TOL, robust_type, lambda_, nanifoutside, del
     prob = eng.problem(1, H, W, C, tt.value, rt.value, nscales, nu, TOL, float(lambda_), bool(nanifoutside is True),
                        int(delta), cts.MAX_ITER)
     p0 = torch.as_tensor(np.asarray(p, dtype=np.float64)[:n]).reshape(1, n)
-    res = eng.solve(_to_device(I1, eng), _to_device(I2, eng), prob, p0=p0, want_images=True, want_trace=bool(verbose))
+    u8 = I1.dtype == np.uint8 and I2.dtype == np.uint8 and C in (1, 3)
+    res = eng.solve(_to_device(I1, eng, u8), _to_device(I2, eng, u8), prob, p0=p0, want_images=True,
+                    want_trace=bool(verbose))
     p_out = res.p[0, :n].cpu().numpy()
     error = float(res.error[0].cpu())
     if verbose:

@@ -51,7 +51,7 @@ class _IcaLayer(torch.nn.Module):
         x = torch.as_tensor(x)
         if x.dim() != 4:
             raise ValueError("I1 and I2 must be batches of images, (B, H, W, C)")
-        x = x.to(device=dev, dtype=torch.float32)
+        x = x.to(device=dev) if x.dtype == torch.uint8 else x.to(device=dev, dtype=torch.float32)  # 8-bit stays 8-bit
         return x.contiguous() if self.channels_first else x.permute(0, 3, 1, 2).contiguous()
 
     def forward(self, inputs: Sequence[torch.Tensor], transform_type: Optional[TransformType] = None):

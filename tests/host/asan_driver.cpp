@@ -14,6 +14,16 @@
 #include "../../inverse_compositional_algorithm_amd/csrc/ica_math.hpp"
 #include "../../inverse_compositional_algorithm_amd/csrc/ica_pyramid.hpp"
 
+// The fused iteration kernel lives in translation units of its own (csrc/ica_iterate_inst.hip, one per transform type);
+// nothing here launches a kernel, so the driver links against stand-ins instead of compiling them five more times.
+#include "../../inverse_compositional_algorithm_amd/csrc/ica_iterate_launch.hpp"
+namespace ica {
+#define ICA_STUB(n) \
+  void launch_iterate_tt##n(int, int, int, unsigned, hipStream_t, const LevelArgs&) { std::abort(); }
+ICA_STUB(1) ICA_STUB(2) ICA_STUB(3) ICA_STUB(4) ICA_STUB(5)
+#undef ICA_STUB
+}  // namespace ica
+
 #define CHECK(cond)                                                        \
   do {                                                                     \
     if (!(cond)) {                                                         \

@@ -94,12 +94,14 @@ def test_hip_reproduces_reference_runs(run):
     np.testing.assert_allclose(float(np.nansum(Iw.astype(np.float64))), run["iw_checksum"], rtol=1e-5)
 
 
-def _hip_solve(run, want_images=False, want_trace=False):
+def _hip_solve(run, want_images=False, want_trace=False, u8=False):
     import torch
     from inverse_compositional_algorithm_amd.engine import IcaEngine
     eng = IcaEngine(0)
     I1, I2 = _inputs(run)
     t, C = run["transform"], run["C"]
+    if u8:  # the generator's pixels are 8-bit values: store them as such
+        I1, I2 = I1.astype(np.uint8), I2.astype(np.uint8)
     d1 = torch.from_numpy(np.ascontiguousarray(np.moveaxis(I1, 2, 0))[None]).to(eng.device)
     d2 = torch.from_numpy(np.ascontiguousarray(np.moveaxis(I2, 2, 0))[None]).to(eng.device)
     prob = eng.problem(1, run["H"], run["W"], C, t, run["robust"], nscales=run["nscales"], nu=run["nu"], tol=run["tol"],
@@ -110,6 +112,21 @@ def _hip_solve(run, want_images=False, want_trace=False):
         prob.lambda0 /= np.sqrt(3.0)
         prob.lambdaN /= np.sqrt(3.0)
     return eng.solve(d1, d2, prob, want_images=want_images, want_trace=want_trace)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("run", CFG_RUNS, ids=CFG_IDS)
+def test_uint8_storage_is_bit_identical_at_baseline_config_sizes(run):
+    """the same pairs with their level-0 images stored as uint8 (a quarter of the bytes in HBM and in the
+    copies).  8-bit values are exact in float32 and the arithmetic is the float path's, so parameters, iteration counts,
+    errors and the NaN masks of the warped image are BIT-identical to the float32-storage solve -- which the test above
+    holds against the reference's goldens."""
+    import torch
+    a = _hip_solve(run, want_images=True)
+    b = _hip_solve(run, want_images=True, u8=True)
+    assert torch.equal(a.p, b.p) and torch.equal(a.niter, b.niter) and torch.equal(a.error, b.error)
+    assert torch.equal(torch.isnan(a.Iw), torch.isnan(b.Iw))
+    assert torch.equal(torch.nan_to_num(a.Iw), torch.nan_to_num(b.Iw)) and torch.equal(torch.nan_to_num(a.DI), torch.nan_to_num(b.DI))
 
 
 @pytest.mark.gpu

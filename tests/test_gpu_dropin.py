@@ -79,7 +79,11 @@ def test_uint8_input_is_cast_like_the_reference():
     a = inverse_compositional_algorithm(I1.astype(np.uint8), I2.astype(np.uint8), np.zeros(2), T.TRANSLATION, 1e-3, True, 5,
                                         False)
     b = inverse_compositional_algorithm(I1, I2, np.zeros(2), T.TRANSLATION, 1e-3, True, 5, False)
+    # (uint8 arrays travel to the GPU and stay there as uint8: same values, same arithmetic, same bits out)
     np.testing.assert_array_equal(a[0], b[0])
+    assert a[1] == b[1]
+    np.testing.assert_array_equal(a[2], b[2])
+    np.testing.assert_array_equal(a[3], b[3])
 
 
 def test_host_pointer_entry_point_matches_device_entry_point():
@@ -106,6 +110,14 @@ def test_host_pointer_entry_point_matches_device_entry_point():
     np.testing.assert_array_equal(nit, ref.niter.cpu().numpy())
     np.testing.assert_array_equal(np.isnan(iw), np.isnan(ref.Iw.cpu().numpy()))
     np.testing.assert_array_equal(np.nan_to_num(di), np.nan_to_num(ref.DI.cpu().numpy()))
+    # uint8 images through the same host-pointer entry point (ica_problem.storage = ICA_STORAGE_U8)
+    u1, u2 = i1.astype(np.uint8), i2.astype(np.uint8)
+    pu, eu, nu_ = np.zeros((B, 8)), np.zeros(B), np.zeros((B, 2), np.int32)
+    prob8 = eng.problem(B, H, W, Cn, t, 0, nscales=2, delta=5, storage=_lib.ICA_STORAGE_U8)
+    st = eng.lib.ica_solve_batch(eng.ctx, C.byref(prob8), ptr(u1), ptr(u2), ptr(pu), ptr(eu), ptr(nu_), None, None, None, None)
+    assert st == 0
+    np.testing.assert_array_equal(pu, p)
+    np.testing.assert_array_equal(nu_, nit)
     # argument errors come back as status codes carrying the reference's messages
     bad = eng.problem(B, H, W, Cn, t, 0, tol=0.01)
     assert eng.lib.ica_solve_batch(eng.ctx, C.byref(bad), ptr(i1), ptr(i2), ptr(p), ptr(err), ptr(nit), None, None, None,

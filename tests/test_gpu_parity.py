@@ -509,3 +509,41 @@ def test_warp_against_scikit_image_outputs(eng, case):
     Iw = to_np(eng.warp(to_dev(eng, img), torch.from_numpy(p[None]), t))[0]
     assert np.array_equal(np.isnan(Iw), np.isnan(want)), name
     np.testing.assert_allclose(np.nan_to_num(Iw), np.nan_to_num(want), atol=2e-3)
+
+
+@pytest.mark.parametrize("t", TYPES)
+@pytest.mark.parametrize("C,W_", [(1, 128), (3, 128), (1, 131), (3, 90)])
+def test_uint8_storage_matches_float_storage_bit_for_bit(eng, t, C, W_):
+    """uint8 level-0 images (ICA_STORAGE_U8): every transform, gray and RGB, L2 and robust, one scale and a pyramid, widths
+    that are / are not a multiple of 4 pixels (whole-group copies vs the element-wise fill), a batch in which pairs
+    converge at different iterations -- results identical to the float32 storage, bit for bit."""
+    n, B, H_ = oc.nparams(t), 5, 96
+    prs = [syn.make_pair(6100 + 13 * t + i, H_, W_, C, t, robust_clutter=True) for i in range(B)]
+    f1, f2 = to_dev(eng, *[a for a, _, _ in prs]), to_dev(eng, *[b for _, b, _ in prs])
+    u1, u2 = f1.to(torch.uint8), f2.to(torch.uint8)
+    assert torch.equal(u1.float(), f1) and torch.equal(u2.float(), f2)
+    for robust, ns in ((oc.QUADRATIC, 2), (oc.CHARBONNIER, 1), (oc.LORENTZIAN, 3)):
+        prob = eng.problem(B, H_, W_, C, t, robust, nscales=ns, delta=4)
+        a = eng.solve(f1, f2, prob, want_images=True, want_trace=True)
+        b = eng.solve(u1, u2, prob, want_images=True, want_trace=True)
+        assert torch.equal(a.p, b.p) and torch.equal(a.niter, b.niter) and torch.equal(a.error, b.error)
+        assert torch.equal(torch.nan_to_num(a.trace), torch.nan_to_num(b.trace))
+        assert torch.equal(torch.isnan(a.Iw), torch.isnan(b.Iw)) and torch.equal(torch.nan_to_num(a.DI), torch.nan_to_num(b.DI))
+    # the operator hook too: H and b of one iteration
+    prob = eng.problem(B, H_, W_, C, t, oc.LORENTZIAN, delta=4)
+    p = np.zeros((B, 8))
+    for i, (_, _, g) in enumerate(prs):
+        p[i, :n] = 0.8 * g
+    Ha, ba = eng.normal_equations(f1, f2, torch.from_numpy(p), prob, lambda_it=30.0)
+    Hb, bb = eng.normal_equations(u1, u2, torch.from_numpy(p), prob, lambda_it=30.0)
+    assert torch.equal(Ha, Hb) and torch.equal(ba, bb)
+
+
+def test_uint8_storage_rejects_what_it_does_not_cover(eng):
+    x = torch.zeros(1, 2, 32, 32, dtype=torch.uint8, device=eng.device)
+    from inverse_compositional_algorithm_amd._lib import IcaError
+    with pytest.raises(IcaError) as e:
+        eng.solve(x, x, eng.problem(1, 32, 32, 2, oc.TRANSLATION, 0))
+    assert e.value.status == -1  # 2- and 4-channel images are float32 only
+    with pytest.raises(ValueError, match="same dtype"):
+        eng.solve(x[:, :1].contiguous(), x[:, :1].float().contiguous(), eng.problem(1, 32, 32, 1, oc.TRANSLATION, 0))
