@@ -189,7 +189,7 @@ __device__ __forceinline__ float rho_prime_t(float t2, float lam2) {
 // workgroup: barrier, expand chunk k, barrier, start the copy of chunk k+1, compute chunk k.
 template <int TT, int MODE, int C, int RT, bool U8>
 // (second launch bound = waves per SIMD the register allocator must leave room for: what the LDS footprint allows)
-__global__ __launch_bounds__(kBlock, (C == 1 ? ICA_ITER_WAVES : 1)) void ica_iterate_kernel(LevelArgs a) {
+__global__ __launch_bounds__(kBlock, (C == 1 ? ICA_ITER_WAVES : U8 ? 3 : 4)) void ica_iterate_kernel(LevelArgs a) {
   using TIn = std::conditional_t<U8, unsigned char, float>;
   constexpr int ES = (int)sizeof(TIn);    // bytes per image element in HBM
   constexpr int N = NP<TT>::n;
@@ -254,8 +254,9 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? ICA_ITER_WAVES : 1)) void ica_ite
   if constexpr (kB) {
     double ad[8];
     params_to_displacement(a.p + (size_t)pair * 8, TT, ad);
+    // (params_to_displacement returns all zeros exactly when it took the identity shortcut)
 #pragma unroll
-    for (int i = 0; i < N; ++i) ident = ident & (fabs(a.p[(size_t)pair * 8 + i]) < 1e-10);
+    for (int i = 0; i < 8; ++i) ident = ident & (ad[i] == 0.0);
 #pragma unroll
     for (int i = 0; i < 8; ++i) A[i] = (float)ad[i];
     lo = a.minmax[pair * 2];
@@ -283,7 +284,8 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? ICA_ITER_WAVES : 1)) void ica_ite
   const bool w4 = (W & 3) == 0;                         // rows start on 4-pixel boundaries -> whole-group LDS-DMA
 
   // ---- plan: lane c (< 32) computes the I2 footprint of chunk c: x_lo | flags (bit 30 = stage through LDS, bit 29 =
-  //      skip, bit 28 = interior: no frame / border / invalid pixel in the chunk), which stays in lane c, and
+  //      skip, bit 28 = interior: no frame / border / invalid pixel in the chunk, bit 27 = every pixel outside the
+  //      NaN frame has its footprint inside I2: frame pixels only need masking), which stays in lane c, and
   //      y_lo | rows << 20, which moves to lane 32 + c of the same register (a tile has at most 32 chunks) ----
   int plan = 0;
   int plan_x = 0, plan_y = 0;
@@ -295,7 +297,9 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? ICA_ITER_WAVES : 1)) void ica_ite
     // the 1-px border where the reference keeps a zero derivative)
     const int mrg = frame_on ? a.delta : 1;
     bool interior = (rows == CH) & (yc0 >= mrg) & (yc0 + CH <= H - mrg) & (x_t0 >= mrg) & (x_t0 + kTileW <= W - mrg);
-    bool stage = false;
+    bool stage = false, semi = false;
+    // (wave-uniform: a tile that does not touch the NaN frame has no border chunk, and skips the second corner test)
+    const bool tile_on_border = (x_t0 < mrg) | (x_t0 + kTileW > W - mrg) | (y_begin < mrg) | (y_end > H - mrg);
     int x_lo = 0, y_lo = 0;
     if constexpr (kB) {
       // the image of the chunk rectangle under an affine / projective map is the convex quadrilateral of its
@@ -329,10 +333,32 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? ICA_ITER_WAVES : 1)) void ica_ite
         plan_y = bh << 20;
         // every footprint inside the image with a pixel to spare: floor(X) - 1 >= 1 and floor(X) + 2 <= W - 2
         interior = interior & (px0 >= 2.0f) & (px1 <= (float)(W - 4)) & (py0 >= 2.0f) & (py1 <= (float)(H - 4));
+        // the same test for the LIVE pixels of the chunk only (those outside the NaN frame): what a border chunk needs
+        if (frame_on & !skip & tile_on_border) {
+          const float lxl = (float)max(x_t0, a.delta), lxr = (float)min(x_t0 + kTileW - 1, W - 1 - a.delta);
+          const float lyt = (float)max(yc0, a.delta), lyb = (float)min(yc0 + rows - 1, H - 1 - a.delta);
+          if (lxl <= lxr && lyt <= lyb) {
+            float ex[4], ey[4];
+            displacement<kProj>(A, lxl, lyt, ex[0], ey[0]);
+            displacement<kProj>(A, lxr, lyt, ex[1], ey[1]);
+            displacement<kProj>(A, lxl, lyb, ex[2], ey[2]);
+            displacement<kProj>(A, lxr, lyb, ex[3], ey[3]);
+            const float qx0 = fminf(fminf(lxl + ex[0], lxr + ex[1]), fminf(lxl + ex[2], lxr + ex[3]));
+            const float qx1 = fmaxf(fmaxf(lxl + ex[0], lxr + ex[1]), fmaxf(lxl + ex[2], lxr + ex[3]));
+            const float qy0 = fminf(fminf(lyt + ey[0], lyt + ey[1]), fminf(lyb + ey[2], lyb + ey[3]));
+            const float qy1 = fmaxf(fmaxf(lyt + ey[0], lyt + ey[1]), fmaxf(lyb + ey[2], lyb + ey[3]));
+            semi = (qx0 >= 2.0f) & (qx1 <= (float)(W - 4)) & (qy0 >= 2.0f) & (qy1 <= (float)(H - 4));
+          } else {
+            semi = true;  // no live pixel in this lane's chunk at all
+          }
+        }
       }
       interior = interior & sane & stage;
+      semi = semi & sane & stage;
+    } else {
+      semi = frame_on;  // no warp in this mode: the frame mask is all a border chunk needs
     }
-    plan_x = x_lo | (stage ? (1 << 30) : 0) | (skip ? (1 << 29) : 0) | (interior ? (1 << 28) : 0);
+    plan_x = x_lo | (stage ? (1 << 30) : 0) | (skip ? (1 << 29) : 0) | (interior ? (1 << 28) : 0) | (semi ? (1 << 27) : 0);
     plan_y |= y_lo;
     const int up = __shfl(plan_y, lane & 31, 64);  // lane 32 + c takes chunk c's word
     plan = lane < 32 ? plan_x : up;
@@ -581,8 +607,13 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? ICA_ITER_WAVES : 1)) void ica_ite
 
     // ---------------------------------------------------------------------------------------------------------
     // INTERIOR chunk: every pixel takes part, every footprint is inside I2 and inside the staged window.
+    // MASKED: a border chunk whose pixels outside the NaN frame all have their footprint inside I2 -- the same
+    // stream, with the frame pixels' residual and weight SELECTED to zero (v_cndmask, not a multiplication by a 0 / 1
+    // mask: a frame pixel samples wherever its position points, possibly at bytes of the uint8 staging area, and the
+    // bits found there may be a NaN).  Coarse pyramid levels consist of such chunks almost entirely.
     // ---------------------------------------------------------------------------------------------------------
-    auto band_fast = [&]() {
+    auto band_fast = [&](auto masked_c) {
+      constexpr bool MASKED = decltype(masked_c)::value;
       // byte address of tap (0,0) of the pixel in row i  =  b2 + ((yb0 + i - 1 - y_lo) * P2 + (x - 1 - x_lo)) * 4
       //                                                     + (floor(dy) * P2 + floor(dx)) * 4;
       // the row part i * P2 * 4 is a compile-time LDS offset, the rest of the first line is computed once per chunk,
@@ -603,6 +634,11 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? ICA_ITER_WAVES : 1)) void ica_ite
 #pragma unroll
       for (int i = 0; i < RW; ++i) {
         const float yf = i == 0 ? yf0 : yf0 + (float)i;  // exact (small integers); a VGPR because yf0 is one
+        [[maybe_unused]] bool live = true;
+        if constexpr (MASKED) {
+          const int y = yb0 + i;  // wave-uniform
+          live = col_ok & (y < y_end) & !((y < a.delta) | (y >= H - a.delta));
+        }
         float ix2[C], iy2[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) {
@@ -627,7 +663,9 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? ICA_ITER_WAVES : 1)) void ica_ite
           float af;  // fly * (P2 * 4) + tap0f with the pitch as a literal (no register for it)
           asm("v_fmamk_f32 %0, %1, %3, %2" : "=v"(af) : "v"(fly), "v"(tap0f), "n"(kPitchBits));
           af = fmaf(flx, 4.0f, af);
-          const unsigned addr = (unsigned)af + (unsigned)(i * P2 * 4);
+          // (signed conversion: in a border chunk the address of row 0 of the band may lie below the tile -- a frame
+          //  row above the image -- while a later, live row of the same band is inside)
+          const unsigned addr = (unsigned)((int)af + i * P2 * 4);
           float wx[4], wy[4];
           keys_weights(fx, wx);
           keys_weights(fy, wy);
@@ -645,6 +683,7 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? ICA_ITER_WAVES : 1)) void ica_ite
               v = (r == 0) ? wy[0] * s : __builtin_fmaf(wy[r], s, v);
             }
             di[c] = __builtin_amdgcn_fmed3f(v, lo, hi_v) - cm[c];  // clip (skimage warp), ref :114
+            if constexpr (MASKED) di[c] = live ? di[c] : 0.0f;
           }
         }
         float w = 1.0f;
@@ -654,6 +693,7 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? ICA_ITER_WAVES : 1)) void ica_ite
           for (int c = 1; c < C; ++c) t2 = fmaf(di[c], di[c], t2);
           w = rho_prime_t<RT>(t2, lam2_v);
         }
+        if constexpr (MASKED && kH) w = live ? w : 0.0f;  // pixels in the NaN frame contribute nothing (derivatives.py:84)
         accumulate(w, ix2, iy2, di, yf);
 #if ICA_ROW_FENCE
         __builtin_amdgcn_sched_barrier(0);  // keep the rows apart: a row hoisted over the previous one's sums costs registers
@@ -776,12 +816,17 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? ICA_ITER_WAVES : 1)) void ica_ite
 #endif
     {
 #if defined(ICA_PROBE) && ICA_PROBE == 1   // register-pressure probe: fast band only
-      band_fast();
+      band_fast(std::false_type{});
 #elif defined(ICA_PROBE) && ICA_PROBE == 2  // careful band only
       if (staged) band_careful(std::true_type{});
       else band_careful(std::false_type{});
 #else
-      if (staged & interior) band_fast();
+      if (staged & interior) band_fast(std::false_type{});
+#ifndef ICA_NO_SEMI
+      // (one channel only: with three, the extra code costs the kernel the registers of an occupancy step -- measured 10 %
+      //  slower on configs[4])
+      else if (C == 1 && staged & ((px & (1 << 27)) != 0)) band_fast(std::true_type{});
+#endif
       else if (staged) band_careful(std::true_type{});
       else band_careful(std::false_type{});
 #endif
