@@ -105,7 +105,7 @@ def cpu_baseline(cfg, mean_iters_per_scale, budget_s=25.0):
         L2.append(oc.rescale_restated(L2[-1], 0.5))
     t_pyr = time.perf_counter() - t0
     setup, per_iter, spent, passes = [0.0] * ns, [0.0] * ns, t_pyr, []
-    per_scale_s = 0.6 * budget_s / ns   # time budget of the loop-body passes of one scale
+    per_scale_s = 0.8 * budget_s / ns   # time budget of the loop-body passes of one scale
     for s in range(ns - 1, -1, -1):   # coarse to fine; the fine scales are the expensive ones
         if spent > budget_s:  # out of budget: extrapolate the remaining (finer) scales by pixel count
             per_iter[s], setup[s] = per_iter[s + 1] * 4.0, setup[s + 1] * 4.0
@@ -140,7 +140,7 @@ def cpu_baseline(cfg, mean_iters_per_scale, budget_s=25.0):
         t0 = time.perf_counter()
         body()
         t1 = time.perf_counter() - t0
-        K = max(2, min(40, int(per_scale_s / max(t1, 1e-6))))  # enough passes for ~per_scale_s seconds at this scale
+        K = max(2, min(400, int(per_scale_s / max(t1, 1e-6))))  # enough passes for ~per_scale_s seconds at this scale
         t0 = time.perf_counter()
         for _ in range(K):
             body()
