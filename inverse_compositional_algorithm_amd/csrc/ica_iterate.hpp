@@ -142,6 +142,7 @@ __device__ __forceinline__ int in_vgpr(int v) {
   asm("" : "+v"(v));
   return v;
 }
+template <int J> using IC = std::integral_constant<int, J>;
 // floor(x) as an integer in one instruction (v_floor_f32 + v_cvt_i32_f32 otherwise)
 __device__ __forceinline__ int floor_to_int(float x) {
   int r;
@@ -363,6 +364,30 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? ICA_ITER_WAVES : U8 ? 3 : 4)) voi
     const int up = __shfl(plan_y, lane & 31, 64);  // lane 32 + c takes chunk c's word
     plan = lane < 32 ? plan_x : up;
   }
+  // Chunks by instruction stream (see the bands below): bit c of a mask = chunk c.  The tile is walked class by class --
+  // interior chunks, then masked-border ones, then the rest -- so that each loop contains ONE band: with two bands
+  // behind a branch in one loop the register allocator keeps the running sums in a second set of registers inside the
+  // straight-line band and copies them back at the back edge (17 + 17 instructions per band, 5 % of its issue time).
+  unsigned cls_mask[3];
+  {
+    const bool mine = (lane < nchunks) & (lane < 32) & !(plan_x & (1 << 29));
+    const bool st = (plan_x & (1 << 30)) != 0, in = (plan_x & (1 << 28)) != 0, se = (plan_x & (1 << 27)) != 0;
+#ifdef ICA_NO_SEMI
+    constexpr bool kSemi = false;
+#else
+    // (one channel only: with three, the extra code costs the kernel the registers of an occupancy step -- measured 10 %
+    //  slower on configs[4])
+    constexpr bool kSemi = (C == 1);
+#endif
+    cls_mask[0] = (unsigned)__ballot(mine & st & in);
+    cls_mask[1] = (unsigned)__ballot(mine & st & !in & se & kSemi);
+    cls_mask[2] = (unsigned)__ballot(mine) & ~(cls_mask[0] | cls_mask[1]);
+#if defined(ICA_PROBE) && ICA_PROBE == 1   // register-pressure probe: fast band only
+    cls_mask[0] |= cls_mask[1] | cls_mask[2]; cls_mask[1] = cls_mask[2] = 0;
+#elif defined(ICA_PROBE) && ICA_PROBE == 2  // careful band only
+    cls_mask[2] |= cls_mask[0] | cls_mask[1]; cls_mask[0] = cls_mask[1] = 0;
+#endif
+  }
   auto plan_px = [&](int k) { return __builtin_amdgcn_readlane(plan, k); };
   auto plan_ylo = [&](int k) { return __builtin_amdgcn_readlane(plan, k + 32) & 0xFFFFF; };
   auto plan_bh = [&](int k) { return __builtin_amdgcn_readlane(plan, k + 32) >> 20; };
@@ -489,9 +514,6 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? ICA_ITER_WAVES : U8 ? 3 : 4)) voi
   hi = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, hi)));
   lam2 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lam2)));
 
-  // Ring protocol: chunk k+1 is in flight while chunk k is computed.  A wave's copies retire in order; the barrier
-  // makes every wave's part visible, and also means everyone has finished reading chunk k-1, whose buffer is the one
-  // chunk k+1 is about to overwrite.
   static_assert(NBUF == 1 || NBUF == 2, "one or two staging buffers");
   // U8: staging area -> float tile, 4 pixels per thread and step; rows whose width is not a multiple of 4 pixels (no
   // whole-group copies) are read straight from memory, element by element (cold path: odd widths at level 0)
@@ -517,19 +539,27 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? ICA_ITER_WAVES : U8 ? 3 : 4)) voi
       }
     }
   };
-  if (U8) {
-    if (w4) issue(0, 0);
-  } else if (NBUF == 2) {
-    issue(0, 0);
+  // first chunk of class >= c that is still to do, -1 if none (all wave-uniform)
+  auto first_from = [&](int c) -> int {
+    for (; c < 3; ++c)
+      if (cls_mask[c]) return __builtin_ctz(cls_mask[c]);
+    return -1;
+  };
+  int ring = 0;  // the float tile the next computed chunk sits in (two tiles: they alternate)
+  {
+    const int k0 = first_from(0);
+    if (k0 >= 0 && ((U8 && w4) || (!U8 && NBUF == 2))) issue(k0, 0);
   }
-  for (int k = 0; k < nchunks; ++k) {
-    const int buf = (NBUF >= 2) ? (k % NBUF) : 0;
+  // one chunk: ring protocol, then the band of its class.  `next` = the chunk that follows in walking order (-1: none).
+  auto step = [&](auto cls_c, const int k, const int next) {
+    constexpr int CLS = decltype(cls_c)::value;
+    const int buf = (NBUF >= 2) ? ring : 0;
     if constexpr (U8) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();   // chunk k's bytes are in the staging area; everyone is done with the float tile
       expand(k);
       __syncthreads();                // the float tile holds chunk k; the staging area is free
-      if (w4 && k + 1 < nchunks) issue(k + 1, 0);
+      if (w4 && next >= 0) issue(next, 0);
     } else if (NBUF == 1) {
       __syncthreads();  // everyone is done reading the single buffer
       issue(k, 0);
@@ -537,13 +567,12 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? ICA_ITER_WAVES : U8 ? 3 : 4)) voi
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      if (k + 1 < nchunks) issue(k + 1, (k + 1) % NBUF);
+      ring ^= 1;
+      if (next >= 0) issue(next, ring);
     }
 
     const int px = plan_px(k), y_lo = plan_ylo(k);
-    if (px & (1 << 29)) continue;
-    const bool staged = (px & (1 << 30)) != 0;
-    const bool interior = (px & (1 << 28)) != 0;
+    [[maybe_unused]] const bool staged = (px & (1 << 30)) != 0;
     const int x_lo = px & 0xFFFFF;
     const float* b2 = lds + buf * TC::buf_floats;
     const float* b1 = b2 + C * P2 * R2;
@@ -665,7 +694,17 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? ICA_ITER_WAVES : U8 ? 3 : 4)) voi
           af = fmaf(flx, 4.0f, af);
           // (signed conversion: in a border chunk the address of row 0 of the band may lie below the tile -- a frame
           //  row above the image -- while a later, live row of the same band is inside)
-          const unsigned addr = (unsigned)((int)af + i * P2 * 4);
+#if defined(ICA_ABLATE) && ICA_ABLATE == 3  // timing-only build: every tap read is lane-linear (no LDS bank conflicts)
+          int zero_s;
+          asm volatile("s_mov_b32 %0, 0" : "=s"(zero_s));
+          const int lane_b = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) * 4;
+          const unsigned addr = (unsigned)(((int)af & zero_s) + lane_b + (lds_b2 + i * P2 * 4));
+#else
+          unsigned addr = (unsigned)((int)af + i * P2 * 4);
+          // (opaque: folded into the read offsets, the row part overflows ds_read2's 8-bit offsets for i >= 1 and
+          //  every pair of taps gets an address add of its own)
+          if (i > 0) asm("" : "+v"(addr));
+#endif
           float wx[4], wy[4];
           keys_weights(fx, wx);
           keys_weights(fy, wy);
@@ -815,22 +854,29 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? ICA_ITER_WAVES : U8 ? 3 : 4)) voi
     if (a.delta < 0)  // timing-only build: staging and barriers only
 #endif
     {
-#if defined(ICA_PROBE) && ICA_PROBE == 1   // register-pressure probe: fast band only
-      band_fast(std::false_type{});
-#elif defined(ICA_PROBE) && ICA_PROBE == 2  // careful band only
-      if (staged) band_careful(std::true_type{});
-      else band_careful(std::false_type{});
-#else
-      if (staged & interior) band_fast(std::false_type{});
-#ifndef ICA_NO_SEMI
-      // (one channel only: with three, the extra code costs the kernel the registers of an occupancy step -- measured 10 %
-      //  slower on configs[4])
-      else if (C == 1 && staged & ((px & (1 << 27)) != 0)) band_fast(std::true_type{});
-#endif
+      if constexpr (CLS == 0) band_fast(std::false_type{});
+      else if constexpr (CLS == 1) band_fast(std::true_type{});
       else if (staged) band_careful(std::true_type{});
       else band_careful(std::false_type{});
-#endif
     }
+  };
+  // Ring protocol (two tiles): chunk `next` is in flight while chunk k is computed.  A wave's copies retire in order;
+  // the barrier makes every wave's part visible, and also means everyone has finished reading the chunk before k,
+  // whose tile is the one `next` is about to overwrite.  Chunks that lie in the NaN frame entirely are in no class.
+  while (cls_mask[0]) {
+    const int k = __builtin_ctz(cls_mask[0]);
+    cls_mask[0] &= cls_mask[0] - 1;
+    step(IC<0>{}, k, first_from(0));
+  }
+  while (cls_mask[1]) {
+    const int k = __builtin_ctz(cls_mask[1]);
+    cls_mask[1] &= cls_mask[1] - 1;
+    step(IC<1>{}, k, first_from(1));
+  }
+  while (cls_mask[2]) {
+    const int k = __builtin_ctz(cls_mask[2]);
+    cls_mask[2] &= cls_mask[2] - 1;
+    step(IC<2>{}, k, first_from(2));
   }
   // The y-moments of one lane's column over the whole tile (<= 64 rows per lane) stay in fp32 registers; they are
   // promoted to fp64 here, before x powers up to x^4 are applied and 64 lanes x 4 waves x tiles are summed.

@@ -133,6 +133,9 @@
 // LDS reads into v40.. (v72 = lane*4 + wave*4096: conflict-free dwords; v73 = lane*8 + ...: for 8-byte reads)
 #define DSR32(d, a, b, c) "ds_read_b32 v" S_(d) ", v72 offset:" S_(a) "*16\n"
 #define DSR2(d, a, b, c) "ds_read2_b32 v[" S_(d) ":" S_(d) "+1], v72 offset0:" S_(a) " offset1:" S_(a) "+1\n"
+// lane stride 4 bytes (v72): every other lane's 8-/16-byte read is misaligned, neighbouring lanes overlap
+#define DSR64U(d, a, b, c) "ds_read_b64 v[" S_(d) ":" S_(d) "+1], v72 offset:" S_(a) "*16+4\n"
+#define DSR128U(d, a, b, c) "ds_read_b128 v[" S_(d) ":" S_(d) "+3], v72 offset:" S_(a) "*16+4\n"
 #define DSR64(d, a, b, c) "ds_read_b64 v[" S_(d) ":" S_(d) "+1], v73 offset:" S_(a) "*16\n"
 
 KERNEL(k_fma3, B16(FMA3), 16)
@@ -205,6 +208,24 @@ KERNEL(k_ds_read_b32_adj, B16(DSR32ADJ) "s_waitcnt lgkmcnt(0)\n", 16)
 KERNEL(k_ds_read_b32_2way, B16(DSR32CONF) "s_waitcnt lgkmcnt(0)\n", 16)
 KERNEL(k_ds_read_b128, REP4(DSR128(40, 1, 0, 0) DSR128(44, 2, 0, 0) DSR128(48, 3, 0, 0) DSR128(52, 4, 0, 0)) "s_waitcnt lgkmcnt(0)\n", 16)
 
+KERNEL(k_ds_read_b64_lane4B, B16P(DSR64U) "s_waitcnt lgkmcnt(0)\n", 16)
+KERNEL(k_ds_read_b128_lane4B, REP4(DSR128U(40, 1, 0, 0) DSR128U(44, 2, 0, 0) DSR128U(48, 3, 0, 0) DSR128U(52, 4, 0, 0)) "s_waitcnt lgkmcnt(0)\n", 16)
+
+// functional check of the misaligned forms: out[lane] = the dwords a lane got from byte address 4*lane+4
+__global__ void k_unaligned_check(float* out) {
+  __shared__ float lds[256];
+  for (int i = threadIdx.x; i < 256; i += 64) lds[i] = (float)i;
+  __syncthreads();
+  const unsigned a = threadIdx.x * 4 + 4;
+  float x0, x1, y0, y1, y2, y3;
+  asm volatile("ds_read_b64 v[20:21], %6\n ds_read_b128 v[24:27], %6\n s_waitcnt lgkmcnt(0)\n"
+               "v_mov_b32 %0, v20\n v_mov_b32 %1, v21\n v_mov_b32 %2, v24\n v_mov_b32 %3, v25\n v_mov_b32 %4, v26\n v_mov_b32 %5, v27\n"
+               : "=v"(x0), "=v"(x1), "=v"(y0), "=v"(y1), "=v"(y2), "=v"(y3) : "v"(a)
+               : "v20", "v21", "v24", "v25", "v26", "v27", "memory");
+  float* o = out + threadIdx.x * 6;
+  o[0] = x0; o[1] = x1; o[2] = y0; o[3] = y1; o[4] = y2; o[5] = y3;
+}
+
 typedef void (*kern_t)(unsigned long long*, int);
 struct Entry { const char* name; kern_t fn; int ninstr; };
 #define E(n, c) {#n, n, c}
@@ -222,7 +243,23 @@ int main(int argc, char** argv) {
       E(k_mul_e64, 16), E(k_mul_const, 16), E(k_add_const, 16), E(k_sub, 16), E(k_max, 16), E(k_cndmask_sgpr, 16),
       E(k_cmp_e64, 16), E(k_cmp_f32, 16), E(k_lshl, 16), E(k_and, 16), E(k_mul_i24, 16), E(k_mad_i24, 16),
       E(k_cvt_f32_i32, 16), E(k_rsq, 16), E(k_mov, 16), E(k_fma_neg, 16), E(k_fmac_const, 16), E(k_cndmask_1in4, 64),
-      E(k_ds_read_b32_adj, 16), E(k_ds_read_b32_2way, 16), E(k_ds_read_b128, 16)};
+      E(k_ds_read_b32_adj, 16), E(k_ds_read_b32_2way, 16), E(k_ds_read_b128, 16),
+      E(k_ds_read_b64_lane4B, 16), E(k_ds_read_b128_lane4B, 16)};
+  {
+    float* dc;
+    (void)hipMalloc(&dc, 64 * 6 * sizeof(float));
+    k_unaligned_check<<<1, 64>>>(dc);
+    std::vector<float> hc(64 * 6);
+    (void)hipMemcpy(hc.data(), dc, hc.size() * sizeof(float), hipMemcpyDeviceToHost);
+    int bad64 = 0, bad128 = 0;
+    for (int l = 0; l < 64; ++l) {
+      for (int j = 0; j < 2; ++j) bad64 += hc[l * 6 + j] != (float)(l + 1 + j);
+      for (int j = 0; j < 4; ++j) bad128 += hc[l * 6 + 2 + j] != (float)(l + 1 + j);
+    }
+    printf("misaligned LDS reads (lane stride 4 B): ds_read_b64 %s, ds_read_b128 %s   lane1: %g %g | %g %g %g %g\n",
+           bad64 ? "WRONG" : "exact", bad128 ? "WRONG" : "exact", hc[6], hc[7], hc[8], hc[9], hc[10], hc[11]);
+    (void)hipFree(dc);
+  }
   if (argc > 1) es.erase(es.begin(), es.begin() + atoi(argv[1]));
   const int iters = 4000;
   unsigned long long* d;
