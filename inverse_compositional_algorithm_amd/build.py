@@ -22,9 +22,12 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 SRC = os.path.join(CSRC, "ica_api.hip")
 LIB = os.path.join(HERE, "libica_hip.so")
 STAMP = LIB + ".stamp"
-# -fno-slp-vectorize: packed fp32 (v_pk_*) buys nothing on gfx950 (one packed instruction issues in the time of two
-# scalar ones) and the register shuffling it needs costs issue slots in the iteration kernel
-CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize"]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+# The iteration kernel's units only.  Packed fp32 (v_pk_*) buys nothing on gfx950 when every operand is a VGPR (one packed
+# instruction issues in the time of two plain ones) and the register shuffling it needs costs issue slots (DESIGN.md
+# section 5).  The pyramid kernels in ica_api.hip keep it: their multiply-adds take a wave-uniform weight from an SGPR,
+# a form that costs 2.1 ns plain and 2.06 ns packed -- two for the price of one.
+NO_SLP = ["-fno-slp-vectorize"]
 
 
 def deps() -> list:
@@ -40,7 +43,7 @@ def units() -> list:
     """(source, extra flags, object name) of every translation unit."""
     inst = os.path.join(CSRC, "ica_iterate_inst.hip")
     return [(os.path.join(CSRC, "ica_api.hip"), [], "ica_api.o")] + \
-           [(inst, [f"-DICA_INST_TT={t}"], f"ica_iterate_tt{t}.o") for t in range(1, 6)]
+           [(inst, NO_SLP + [f"-DICA_INST_TT={t}"], f"ica_iterate_tt{t}.o") for t in range(1, 6)]
 
 
 def hipcc() -> str:

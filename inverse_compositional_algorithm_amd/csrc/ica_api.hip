@@ -45,16 +45,18 @@ struct DevBuf {
 };
 
 struct DeviceBandOp {
-  DevBuf start, wT, vj0, vspan, vown0, vown1, vw;
+  DevBuf start, wT, vj0, vspan, vown0, vown1, vw, vwslot, hc0;
   int n_in = 0, n_out = 0, K = 0;
+  int hnb = 0, hblocks = 0;  // fused step, this operator on the x axis: outputs per column block (0: not usable), blocks
   int vspan_max = 0;   // widest input span of kOutsV consecutive outputs (window of the vertical pass)
   int span_pad = 0;    // LDS row pitch (floats) of the horizontal pass: widest 64-output input span, made odd
   bool vcover = false; // the groups' "own" ranges cover the whole input axis (min/max can be folded into the pass)
   BandOp view() const {
     return BandOp{start.as<int>(), wT.as<float>(), vj0.as<int>(), vspan.as<int>(), vown0.as<int>(), vown1.as<int>(),
-                  vw.as<float>(), n_in, n_out, K};
+                  vw.as<float>(), vwslot.as<int>(), n_in, n_out, K};
   }
-  void release() { start.release(); wT.release(); vj0.release(); vspan.release(); vown0.release(); vown1.release(); vw.release(); }
+  FusedCols cols() const { return FusedCols{hc0.as<int>(), hnb}; }
+  void release() { start.release(); wT.release(); vj0.release(); vspan.release(); vown0.release(); vown1.release(); vw.release(); vwslot.release(); hc0.release(); }
 };
 
 struct LevelGeom {
@@ -73,12 +75,13 @@ struct ica_ctx {
   int accum_variant = 2;           // ICA_ACCUM=1: the direct-gather iteration kernel (in-library cross-check)
   bool fold_hessian = true;        // ICA_SEPARATE_HESSIAN=1: separate L2 Hessian pass per level
   int max_tile_h = 512;            // ICA_MAX_TILE_H
+  bool fused_pyramid = true;       // ICA_PYRAMID_2PASS=1: vertical and horizontal pyramid passes as two kernels
   double board_timeout_s = 10.0;   // ICA_BOARD_TIMEOUT_MS: how long the host waits for an iteration's count
   std::string last_error;
   // workspaces
   DevBuf pyr1[ICA_MAX_SCALES], pyr2[ICA_MAX_SCALES];  // levels >= 1
   DevBuf tmp_resample;                                // intermediate of the separable pyramid pass
-  DevBuf partials, hinv, p_prev, lambda_it, error, niter, lists, counts, count_hist, minmax, mm_part, mm_in;
+  DevBuf partials, hinv, p_prev, lambda_it, error, niter, lists, counts, count_hist, minmax, mm_part, mm_in, out_part;
   DevBuf scratch_p;
   int* pinned_count = nullptr;   // one list's shard counters for synchronous reads + a [scales][max_iter] board the kernels post to
   int* board = nullptr;          // host pointer of the board (pinned, host-coherent)
@@ -96,7 +99,7 @@ struct ica_ctx {
     if (handover) (void)hipEventDestroy(handover);
     for (int i = 0; i < ICA_MAX_SCALES; ++i) { pyr1[i].release(); pyr2[i].release(); }
     DevBuf* all[] = {&tmp_resample, &partials, &hinv, &p_prev, &lambda_it, &error, &niter, &lists, &counts,
-                     &count_hist, &minmax, &mm_part, &mm_in, &scratch_p};
+                     &count_hist, &minmax, &mm_part, &mm_in, &out_part, &scratch_p};
     for (auto* b : all) b->release();
     if (pinned_count) (void)hipHostFree(pinned_count);
     if (board) (void)hipHostFree(board);
@@ -180,19 +183,39 @@ int get_op(ica_ctx* ctx, int n_in, int n_out, DeviceBandOp** out) {
   // vertical pass: per group of kOutsV outputs, a zero-padded window of weights indexed by input row
   const int groups = (n_out + kOutsV - 1) / kOutsV;
   std::vector<int> vj0(groups), vspan(groups);
-  std::vector<float> vw((size_t)groups * kVWin * kOutsV, 0.0f);
+  std::vector<float> vw;           // distinct windows, [slot][kVWin][kOutsV]
+  std::vector<int> vwslot(groups, 0);
+  std::vector<float> win((size_t)kVWin * kOutsV);
   for (int g = 0; g < groups; ++g) {
     const int o0 = g * kOutsV, no = std::min(kOutsV, n_out - o0);
     vj0[g] = h.start[o0];
     vspan[g] = std::min(n_in, h.start[o0 + no - 1] + h.K) - vj0[g];
     d->vspan_max = std::max(d->vspan_max, vspan[g]);
     if (vspan[g] > kVWin) continue;  // rejected by the caller
+    std::fill(win.begin(), win.end(), 0.0f);
     for (int i = 0; i < no; ++i)
       for (int k = 0; k < h.K; ++k) {
         const int jj = h.start[o0 + i] + k - vj0[g];
-        if (jj >= 0 && jj < vspan[g]) vw[((size_t)g * kVWin + jj) * kOutsV + i] = (float)h.w[(size_t)(o0 + i) * h.K + k];
+        if (jj >= 0 && jj < vspan[g]) win[(size_t)jj * kOutsV + i] = (float)h.w[(size_t)(o0 + i) * h.K + k];
       }
+    // same window as an earlier group (to the last bit or two: the entries come out of a float64 recursion)?
+    int slot = -1;
+    const int nslots = (int)(vw.size() / win.size());
+    for (int t = nslots - 1; t >= 0 && t >= nslots - 4 && slot < 0; --t) {
+      float dmax = 0.f;
+      for (size_t e = 0; e < win.size(); ++e) dmax = std::max(dmax, std::fabs(vw[(size_t)t * win.size() + e] - win[e]));
+      if (dmax <= 1.2e-7f) slot = t;
+    }
+    if (slot < 0) {
+      slot = nslots;
+      vw.insert(vw.end(), win.begin(), win.end());
+    }
+    vwslot[g] = slot;
   }
+  if (vw.empty()) vw.assign(win.size(), 0.0f);
+  if (getenv("ICA_DEBUG_OPS"))
+    fprintf(stderr, "ica: rescale operator %d -> %d: K %d, %d groups of %d outputs, %d distinct weight windows\n", n_in, n_out,
+            h.K, groups, kOutsV, (int)(vw.size() / win.size()));
   // partition of the input axis among the groups (for the fused min/max): cut at the middle of each overlap
   std::vector<int> vown0(groups), vown1(groups);
   d->vcover = vj0[0] == 0 && vj0[groups - 1] + vspan[groups - 1] == n_in;
@@ -208,6 +231,23 @@ int get_op(ica_ctx* ctx, int n_in, int n_out, DeviceBandOp** out) {
     for (int o = 0; o < n_out; o += 64) span = std::max(span, h.start[std::min(o + 63, n_out - 1)] + h.K - h.start[o]);
     d->span_pad = span | 1;
   }
+  // fused step (ica_resample_fused_kernel): column blocks of `hnb` outputs whose input span, from a 16-byte aligned
+  // first column, fits the kFusedW columns a wave holds; starts are non-decreasing, so the last output decides
+  std::vector<int> hc0;
+  {
+    auto fits = [&](int nb) {
+      for (int ob = 0; ob < n_out; ob += nb)
+        if (h.start[std::min(ob + nb, n_out) - 1] + h.K - (h.start[ob] & ~3) > kFusedW) return false;
+      return true;
+    };
+    int nb = 128;
+    while (nb >= 16 && !fits(nb)) nb -= 8;
+    if (nb >= 16) {
+      d->hnb = nb;
+      d->hblocks = (n_out + nb - 1) / nb;
+      for (int ob = 0; ob < n_out; ob += nb) hc0.push_back(h.start[ob] & ~3);
+    }
+  }
   auto up = [&](DevBuf& b, const void* src, size_t bytes) -> hipError_t {
     hipError_t e = b.ensure(bytes);
     if (e == hipSuccess) e = hipMemcpy(b.ptr, src, bytes, hipMemcpyHostToDevice);
@@ -220,6 +260,8 @@ int get_op(ica_ctx* ctx, int n_in, int n_out, DeviceBandOp** out) {
   if (e == hipSuccess) e = up(d->vown0, vown0.data(), vown0.size() * sizeof(int));
   if (e == hipSuccess) e = up(d->vown1, vown1.data(), vown1.size() * sizeof(int));
   if (e == hipSuccess) e = up(d->vw, vw.data(), vw.size() * sizeof(float));
+  if (e == hipSuccess) e = up(d->vwslot, vwslot.data(), vwslot.size() * sizeof(int));
+  if (e == hipSuccess && !hc0.empty()) e = up(d->hc0, hc0.data(), hc0.size() * sizeof(int));
   if (e != hipSuccess) {
     ctx->last_error = std::string("pyramid operator upload: ") + hipGetErrorString(e);
     d->release();
@@ -256,12 +298,45 @@ int launch_pyramid_down(ica_ctx* ctx, int batch, int C, int H, int W, int h, int
   const int planes = batch * C;
   const size_t lds = (size_t)kRowsH * ox->span_pad * sizeof(float);
   const bool generic_v = oy->vspan_max > kVWin, generic_h = lds > 64 * 1024;
-  ICA_HIP(ctx, ctx->tmp_resample.ensure((size_t)planes * h * W * sizeof(float)));
-  float* tmp = ctx->tmp_resample.as<float>();
   // 4 columns per lane (one 16-byte load, or one dword of uint8 pixels) in the vertical pass when rows and base
   // pointers are aligned for it, else one column per lane
   const bool vec4 = W % 4 == 0 && ((uintptr_t)in % (4 * sizeof(TIn))) == 0;
   constexpr bool kF32 = std::is_same<TIn, float>::value;
+  if (ctx->fused_pyramid && vec4 && !generic_v && ox->hnb > 0) {
+    // both passes in one kernel (ica_resample_fused_kernel): no intermediate image
+    const int vgroups = (h + kOutsV - 1) / kOutsV, xb = ox->hblocks;
+    const int per_pair = C * vgroups * xb;
+    float* part = nullptr;
+    if (oy->vcover) {
+      ICA_HIP(ctx, ctx->mm_part.ensure((size_t)batch * per_pair * 2 * sizeof(float)));
+      part = ctx->mm_part.as<float>();
+    } else {
+      ICA_TRY(launch_minmax(ctx, batch, (size_t)C * H * W, in, mm_out));
+    }
+    ICA_HIP(ctx, ctx->out_part.ensure((size_t)batch * per_pair * 2 * sizeof(float)));
+    float* opart = ctx->out_part.as<float>();
+    const int step = std::max(C, (32768 / C) * C);  // planes ride on grid.z: chunk on whole pairs
+    for (int p0 = 0; p0 < planes; p0 += step) {
+      const int np = std::min(step, planes - p0);
+      const size_t po = (size_t)p0 * vgroups * xb * 2;
+      hipLaunchKernelGGL((ica_resample_fused_kernel<TIn>), dim3(xb, (vgroups + kWaves - 1) / kWaves, np), dim3(kBlock), 0,
+                         ctx->stream, in + (size_t)p0 * H * W, out + (size_t)p0 * h * w, W, oy->view(), ox->view(),
+                         ox->cols(), part ? part + po : nullptr, opart + po);
+    }
+    if (part)
+      hipLaunchKernelGGL(ica_minmax_final_kernel, dim3((batch + kWaves - 1) / kWaves), dim3(kBlock), 0, ctx->stream, part,
+                         per_pair, batch, mm_out);
+    for (int p0 = 0; p0 < planes; p0 += step) {
+      const int np = std::min(step, planes - p0);
+      hipLaunchKernelGGL(ica_resample_clip_kernel, dim3(xb, (vgroups + kWaves - 1) / kWaves, np), dim3(kBlock), 0, ctx->stream,
+                         out + (size_t)p0 * h * w, C, h, w, ox->hnb, opart + (size_t)p0 * vgroups * xb * 2,
+                         mm_out + (size_t)(p0 / C) * 2);
+    }
+    ICA_HIP(ctx, hipGetLastError());
+    return ICA_OK;
+  }
+  ICA_HIP(ctx, ctx->tmp_resample.ensure((size_t)planes * h * W * sizeof(float)));
+  float* tmp = ctx->tmp_resample.as<float>();
   const int vgroups = (h + kOutsV - 1) / kOutsV, xblocks = vec4 ? (W + 255) / 256 : (W + 63) / 64;
   const int per_pair = C * vgroups * xblocks;  // min/max partials per pair written by the vertical pass
   float* part = nullptr;
@@ -475,6 +550,7 @@ int ica_create(int device, ica_ctx** out) {
   if (const char* e = getenv("ICA_ACCUM")) c->accum_variant = (atoi(e) == 1) ? 1 : 2;
   if (const char* e = getenv("ICA_SEPARATE_HESSIAN")) c->fold_hessian = atoi(e) == 0;
   if (const char* e = getenv("ICA_MAX_TILE_H")) c->max_tile_h = std::max(16, atoi(e));
+  if (const char* e = getenv("ICA_PYRAMID_2PASS")) c->fused_pyramid = atoi(e) == 0;
   if (const char* e = getenv("ICA_BOARD_TIMEOUT_MS")) c->board_timeout_s = std::max(1, atoi(e)) * 1e-3;
   *out = c;
   return ICA_OK;

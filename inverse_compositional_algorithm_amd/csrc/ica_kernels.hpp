@@ -607,11 +607,17 @@ struct BandOp {
   const int* vspan;    // [groups] input samples spanned by the group
   const int* vown0;    // [groups] the groups' windows overlap; [vown0, vown1) partitions the input axis so that the
   const int* vown1;    //          vertical pass can fold the image's min/max into its single read
-  const float* vw;     // [groups][kVWin][kOutsV] zero-padded weight window, kOutsV outputs interleaved
+  const float* vw;     // [slots][kVWin][kOutsV] zero-padded weight windows, kOutsV outputs interleaved
+  const int* vwslot;   // [groups] the group's window.  Groups with the same window share a slot: away from the image
+                       // border a decimation by an integer factor is shift-invariant, the whole table is then a few KB
+                       // and the weight fetches (scalar loads, one row of weights per input row) stay in the scalar cache
   int n_in, n_out, K;
 };
 
-constexpr int kOutsV = 16;   // consecutive output rows per wave in the vertical pass
+#ifndef ICA_OUTSV
+#define ICA_OUTSV 16
+#endif
+constexpr int kOutsV = ICA_OUTSV;   // consecutive output rows per wave in the vertical pass
 constexpr int kVWin = 160;   // max input samples spanned by 16 consecutive outputs (16*f + K), checked on the host
 constexpr int kRowsH = 32;   // rows per workgroup in the horizontal pass (8 per wave)
 
@@ -639,7 +645,7 @@ __global__ __launch_bounds__(kBlock) void ica_resample_v_kernel(const TIn* __res
   const int no = min(kOutsV, op.n_out - o0);
   const int j0 = op.vj0[g], span = op.vspan[g];
   const int own0 = mm_part ? op.vown0[g] - j0 : 0, own1 = mm_part ? op.vown1[g] - j0 : 0;
-  const float* __restrict__ wz = op.vw + (size_t)g * kVWin * kOutsV;
+  const float* __restrict__ wz = op.vw + (size_t)op.vwslot[g] * kVWin * kOutsV;
   float acc[kOutsV][VEC];
 #pragma unroll
   for (int i = 0; i < kOutsV; ++i)
@@ -808,6 +814,205 @@ __global__ __launch_bounds__(kBlock) void ica_resample_h_kernel(const float* __r
     const int y = r_base + rg * 8 + i;
     if (y < H) out[((size_t)pl * H + y) * op.n_out + o] = fminf(fmaxf(acc[i], lo), hi);
   }
+}
+
+// ---- both passes in one kernel --------------------------------------------------------------------------------------
+// The two-pass pyramid step moves 9 bytes per input pixel at factor 2 (read 4, write 2, read 2, write 1); producing the
+// level in one kernel moves 5.  A wave takes kOutsV output rows x one column block: the vertical pass exactly as above
+// over the block's kFusedW input columns (4 per lane), whose result -- 16 rows x 256 columns -- never leaves the CU: it
+// goes through a wave-private LDS tile (8 rows at a time, de-interleaved like the horizontal pass's) and the same lanes
+// apply the horizontal operator, two output columns each.  Column blocks overlap by the horizontal band (K - f of 256
+// columns: 10 % at factor 2), which the L2 serves.
+//
+// The clip range is the min/max of the INPUT image, which this very kernel is still computing (folded into its only read
+// of the input, like the vertical pass).  So the output is written unclipped together with each wave's own output
+// range; once the pair's range is final (ica_minmax_final_kernel), ica_resample_clip_kernel revisits only the
+// (wave) tiles whose range sticks out of it -- in practice the few that contain an overshoot next to a saturated
+// region -- and clips them.  Same values as clipping every pixel, without a second pass over the data.
+constexpr int kFusedW = 256;     // input columns per column block
+#ifndef ICA_FUSED_HALF
+#define ICA_FUSED_HALF 8
+#endif
+constexpr int kFusedHalf = ICA_FUSED_HALF;    // rows per horizontal half pass (LDS: 8 x 256 floats per wave)
+
+struct FusedCols {
+  const int* c0;   // [blocks] first input column of each block (multiple of 4)
+  int nb;          // output columns per block (<= 128: two per lane)
+};
+
+template <class TIn>
+__global__ __launch_bounds__(kBlock) void ica_resample_fused_kernel(const TIn* __restrict__ in, float* __restrict__ out,
+                                                                    int W, BandOp oy, BandOp ox, FusedCols fc,
+                                                                    float* __restrict__ mm_part, float* __restrict__ out_part) {
+  typedef float vec4f __attribute__((ext_vector_type(4)));
+  typedef float vec2f __attribute__((ext_vector_type(2)));
+  __shared__ __attribute__((aligned(16))) float tiles[kWaves][kFusedHalf][kFusedW];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = blockIdx.y * kWaves + wave;
+  const int o0 = g * kOutsV;
+  const int pl = blockIdx.z;
+  if (o0 >= oy.n_out) return;  // whole wave (the LDS tiles are wave-private: no workgroup barrier anywhere)
+  const int no = min(kOutsV, oy.n_out - o0);
+  const int c0 = fc.c0[blockIdx.x];
+  const int x = c0 + 4 * lane;
+  const int j0 = oy.vj0[g], span = oy.vspan[g];
+  const int own0 = mm_part ? oy.vown0[g] - j0 : 0, own1 = mm_part ? oy.vown1[g] - j0 : 0;
+  const float* __restrict__ wz = oy.vw + (size_t)oy.vwslot[g] * kVWin * kOutsV;
+  float acc[kOutsV][4];
+#pragma unroll
+  for (int i = 0; i < kOutsV; ++i)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[i][v] = 0.f;
+  const bool xin = x < W;  // (W % 4 == 0: a lane's four columns are in or out together)
+  const TIn* col = in + (size_t)pl * oy.n_in * W + (size_t)j0 * W + (xin ? x : 0);
+  float lo = INFINITY, hi = -INFINITY;
+  float (*tile)[kFusedW] = tiles[wave];
+  // (Built and measured instead of the plain loads below: the rows through a ring of 8 LDS-DMA slots in the wave's idle
+  //  tile, 8 KB in flight per wave and no registers spent.  Next to the DMA intrinsic the compiler no longer keeps the
+  //  wave-uniform weights on the scalar path, and with hand-written s_load + wait per row the scalar-cache misses of
+  //  the 3.6 KB weight window sit exposed in every row: 2.36 ms against 1.95 ms for the 1024^2 level.)
+#ifndef ICA_FUSED_UNROLL
+#define ICA_FUSED_UNROLL 4
+#endif
+  // (Also built and measured, none of them moving the 1024^2 level off ~2.0 ms: 2 / 6 / 8 rows of loads in flight; 8
+  //  output rows per wave at 64 registers and twice the waves; the block's horizontal weights staged in LDS; odd groups
+  //  walking their window bottom-up so that the rows two neighbours share are read close in time.  Counters
+  //  (profiles/r02_pyramid_fused_counters.txt): 1.7x the input fetched from HBM -- the overlap of the windows, 57 rows
+  //  per 32 new ones, mostly misses the L2 -- at 3.7 TB/s, the vector ALU half busy with the zero-padded windows' 2.3x
+  //  multiply-adds, the LDS pipe a quarter busy: three moderately loaded resources that do not overlap well in one wave.)
+  auto run = [&](int a, int b, auto track_c) {
+    constexpr bool TRACK = decltype(track_c)::value;
+#pragma unroll ICA_FUSED_UNROLL
+    for (int jj = a; jj < b; ++jj) {
+      float val[4];
+      if constexpr (std::is_same_v<TIn, float>) {
+        const vec4f v4 = *reinterpret_cast<const vec4f*>(col + (size_t)jj * W);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) val[v] = v4[v];
+      } else {
+        const unsigned u = *reinterpret_cast<const unsigned*>(col + (size_t)jj * W);
+        val[0] = (float)(u & 0xffu); val[1] = (float)((u >> 8) & 0xffu); val[2] = (float)((u >> 16) & 0xffu); val[3] = (float)(u >> 24);
+      }
+      if constexpr (TRACK) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { lo = fminf(lo, val[v]); hi = fmaxf(hi, val[v]); }
+      }
+#pragma unroll
+      for (int i = 0; i < kOutsV; ++i) {
+        const float w = wz[jj * kOutsV + i];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[i][v] = fmaf(w, val[v], acc[i][v]);
+      }
+    }
+  };
+  if (xin) {  // (columns past the image stay zero: the horizontal weights that reach them are zero as well)
+    run(0, own0, std::false_type{});
+    run(own0, own1, std::true_type{});
+    run(own1, span, std::false_type{});
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  // ---- horizontal operator on the wave's 16 x 256 block, 8 rows at a time through LDS ----
+  const int ob = blockIdx.x * fc.nb, oe = min(ob + fc.nb, ox.n_out);
+  float olo = INFINITY, ohi = -INFINITY;
+#pragma unroll
+  for (int hh = 0; hh < kOutsV / kFusedHalf; ++hh) {
+    // relative column c = 4 * lane + v goes to plane (c & 1), slot (c >> 1): evens at [0, 128), odds at [128, 256)
+#pragma unroll
+    for (int i = 0; i < kFusedHalf; ++i) {
+      vec2f ev, od;
+      ev[0] = acc[hh * kFusedHalf + i][0]; ev[1] = acc[hh * kFusedHalf + i][2];
+      od[0] = acc[hh * kFusedHalf + i][1]; od[1] = acc[hh * kFusedHalf + i][3];
+      *reinterpret_cast<vec2f*>(&tile[i][2 * lane]) = ev;
+      *reinterpret_cast<vec2f*>(&tile[i][kFusedW / 2 + 2 * lane]) = od;
+    }
+    // the tile is this wave's own and a wave's LDS operations execute in order: only the compiler has to be told
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int slot = 0; slot < 2; ++slot) {
+      const int o = ob + lane + 64 * slot;
+      const bool valid = o < oe;
+      const int s = valid ? ox.start[o] - c0 : 0;  // s + K <= 256 for every output of the block (host-checked)
+      float a8[kFusedHalf];
+#pragma unroll
+      for (int i = 0; i < kFusedHalf; ++i) a8[i] = 0.f;
+      // The weights are per-lane global loads (L1 / L2 hits, but a round trip each): 16 at a time, all in flight together.
+      // (Staging the block's weights in LDS once per workgroup was built and measured too: the extra 12.8 KB cost an
+      //  occupancy step and the pass got slower, 2.2 ms against 1.95 ms for the 1024^2 level.)
+      const float* wcol = ox.wT + (valid ? o : 0);
+      for (int k0 = 0; k0 < ox.K; k0 += 16) {
+        float wk[16];
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) wk[kk] = (valid && k0 + kk < ox.K) ? wcol[(size_t)(k0 + kk) * ox.n_out] : 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+          if (k0 + kk < ox.K) {  // wave-uniform
+            const int c = s + k0 + kk;
+            const float* q = &tile[0][(c & 1) * (kFusedW / 2) + (c >> 1)];
+#pragma unroll
+            for (int i = 0; i < kFusedHalf; ++i) a8[i] = fmaf(wk[kk], q[i * kFusedW], a8[i]);
+          }
+        }
+      }
+      if (valid) {
+#pragma unroll
+        for (int i = 0; i < kFusedHalf; ++i) {
+          const int r = hh * kFusedHalf + i;
+          if (r < no) {
+            out[((size_t)pl * oy.n_out + o0 + r) * ox.n_out + o] = a8[i];
+            olo = fminf(olo, a8[i]);
+            ohi = fmaxf(ohi, a8[i]);
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // everyone has read this half before the next one overwrites it
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    lo = fminf(lo, __shfl_down(lo, off, 64));
+    hi = fmaxf(hi, __shfl_down(hi, off, 64));
+    olo = fminf(olo, __shfl_down(olo, off, 64));
+    ohi = fmaxf(ohi, __shfl_down(ohi, off, 64));
+  }
+  if (lane == 0) {
+    const int ngroups = (oy.n_out + kOutsV - 1) / kOutsV;
+    const size_t slot = ((size_t)pl * ngroups + g) * gridDim.x + blockIdx.x;  // [plane][group][column block]
+    if (mm_part) { mm_part[slot * 2] = lo; mm_part[slot * 2 + 1] = hi; }
+    out_part[slot * 2] = olo;
+    out_part[slot * 2 + 1] = ohi;
+  }
+}
+
+// Clip the (wave) tiles of a fused pyramid step whose output range leaves the pair's input range (see above): one wave
+// per tile, same grid as the step itself.  (One THREAD per tile's range check with the flagged tiles clipped by the wave
+// one after the other was slower, 0.48 ms against 0.17 ms on the benchmark's 1024^2 level: images with saturated
+// regions flag many tiles, and those want to be clipped in parallel.)
+__global__ __launch_bounds__(kBlock) void ica_resample_clip_kernel(float* __restrict__ out, int channels, int n_out_y, int n_out_x,
+                                                                   int nb, const float* __restrict__ out_part,
+                                                                   const float* __restrict__ minmax) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = blockIdx.y * kWaves + wave, o0 = g * kOutsV, pl = blockIdx.z;
+  if (o0 >= n_out_y) return;
+  const int ngroups = (n_out_y + kOutsV - 1) / kOutsV;
+  const size_t slot = ((size_t)pl * ngroups + g) * gridDim.x + blockIdx.x;
+  const int pair = pl / channels;
+  const float lo = minmax[pair * 2], hi = minmax[pair * 2 + 1];
+  if (out_part[slot * 2] >= lo && out_part[slot * 2 + 1] <= hi) return;
+  const int no = min(kOutsV, n_out_y - o0);
+  const int ob = blockIdx.x * nb, oe = min(ob + nb, n_out_x);
+  for (int r = 0; r < no; ++r)
+    for (int o = ob + lane; o < oe; o += 64) {
+      float* q = out + ((size_t)pl * n_out_y + o0 + r) * n_out_x + o;
+      *q = fminf(fmaxf(*q, lo), hi);
+    }
 }
 
 // Generic banded pass for downsampling factors the tiled passes are not sized for (a window of 16 outputs wider than

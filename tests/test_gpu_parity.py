@@ -191,6 +191,51 @@ def test_pyramid_down_other_factors(eng, nu):
         np.testing.assert_allclose(got[i], want, atol=2e-4)
 
 
+@pytest.fixture(scope="module")
+def eng_two_pass():
+    """A second context whose pyramid steps run as two kernels (vertical, then horizontal + clip)."""
+    import os
+    os.environ["ICA_PYRAMID_2PASS"] = "1"
+    try:
+        from inverse_compositional_algorithm_amd.engine import IcaEngine
+        e = IcaEngine(0)
+    finally:
+        del os.environ["ICA_PYRAMID_2PASS"]
+    return e
+
+
+def _saturated_image(rng, H_, W_, C):
+    """Smooth texture with flat 0 / 255 regions: the cubic prefilter overshoots next to them, so the clip to the input's
+    range (skimage.rescale) is active."""
+    img = np.round(rng.uniform(40, 215, (H_, W_, C)))
+    img[H_ // 5:H_ // 2, W_ // 6:W_ // 2] = 255.0
+    img[H_ // 2 + 3:H_ - 7, W_ // 2 + 5:W_ - 9] = 0.0
+    img[3:9, 5:W_ - 5] = 255.0
+    return img
+
+
+@pytest.mark.parametrize("shape,C,nu", [((64, 1024), 1, 0.5), ((200, 600), 3, 0.5), ((96, 512), 1, 0.5), ((150, 400), 1, 0.75),
+                                        ((180, 256), 1, 0.3), ((37, 1028), 1, 0.5)])
+def test_pyramid_down_single_kernel(eng, eng_two_pass, shape, C, nu):
+    """Widths that are a multiple of 4 run both passes in one kernel (several overlapping column blocks; output written
+    unclipped, tiles outside the input range revisited).  Same values as the two-kernel step, bit for bit, and both
+    agree with the restated skimage.rescale; the images have saturated regions so that the clip matters."""
+    H_, W_ = shape
+    rng = np.random.default_rng(H_ * 7 + W_ + C)
+    imgs = [_saturated_image(rng, H_, W_, C), np.round(rng.uniform(0, 255, (H_, W_, C)))]
+    got = to_np(eng.pyramid_down(to_dev(eng, *imgs), nu))
+    two = to_np(eng_two_pass.pyramid_down(to_dev(eng_two_pass, *imgs), nu))
+    clipped = 0
+    for i in range(2):
+        want = oc.rescale_restated(imgs[i], nu)
+        assert got[i].shape == want.shape
+        np.testing.assert_array_equal(got[i], two[i])
+        np.testing.assert_allclose(got[i], want, atol=2e-4)
+        assert got[i].min() >= imgs[i].min() and got[i].max() <= imgs[i].max()
+        clipped += int(np.sum((got[i] == imgs[i].max()) | (got[i] == imgs[i].min())))
+    assert clipped > 0  # the saturated image does get clipped
+
+
 @pytest.mark.parametrize("nu", [0.1, 0.07])
 def test_pyramid_down_very_small_factor(eng, nu):
     """The reference accepts any nu; factors below ~0.12 exceed what the tiled passes are sized for and run the generic
