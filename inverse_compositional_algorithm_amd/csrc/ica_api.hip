@@ -289,9 +289,12 @@ int launch_minmax(ica_ctx* ctx, int batch, size_t elems, const TIn* img, float* 
 // One pyramid step.  `mm_out` ([batch][2]) receives the min/max of `in` (the clip range of skimage's rescale, and --
 // for I2 -- of the warp at that level); it is folded into the vertical pass, which reads every pixel of `in` anyway.
 // TIn: element type of `in` (uint8 for the level-0 images of an ICA_STORAGE_U8 problem); `out` is always float32.
+// `mm_next` (optional): the min/max of `out`, when the step can give it for free (single-kernel step: from the tiles'
+// ranges); *have_next says whether it was written.
 template <class TIn>
 int launch_pyramid_down(ica_ctx* ctx, int batch, int C, int H, int W, int h, int w, const TIn* in, float* out,
-                        float* mm_out) {
+                        float* mm_out, float* mm_next = nullptr, bool* have_next = nullptr) {
+  if (have_next) *have_next = false;
   DeviceBandOp *ox = nullptr, *oy = nullptr;
   ICA_TRY(get_op(ctx, W, w, &ox));
   ICA_TRY(get_op(ctx, H, h, &oy));
@@ -331,6 +334,11 @@ int launch_pyramid_down(ica_ctx* ctx, int batch, int C, int H, int W, int h, int
       hipLaunchKernelGGL(ica_resample_clip_kernel, dim3(xb, (vgroups + kWaves - 1) / kWaves, np), dim3(kBlock), 0, ctx->stream,
                          out + (size_t)p0 * h * w, C, h, w, ox->hnb, opart + (size_t)p0 * vgroups * xb * 2,
                          mm_out + (size_t)(p0 / C) * 2);
+    }
+    if (mm_next) {
+      hipLaunchKernelGGL(ica_minmax_clipped_kernel, dim3((batch + kWaves - 1) / kWaves), dim3(kBlock), 0, ctx->stream, opart,
+                         per_pair, batch, mm_out, mm_next);
+      if (have_next) *have_next = true;
     }
     ICA_HIP(ctx, hipGetLastError());
     return ICA_OK;
@@ -641,23 +649,26 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const void* I1v, co
   ICA_HIP(ctx, ctx->minmax.ensure((size_t)ns * B * 2 * sizeof(float)));
   ICA_HIP(ctx, ctx->mm_in.ensure((size_t)B * 2 * sizeof(float)));
   float* mm2 = ctx->minmax.as<float>();
+  bool have_coarsest = false;  // the coarsest I2 level's range, needed by its warp, may come out of the last step
   for (int s = 1; s < ns; ++s) {
+    float* mm_next = s == ns - 1 ? mm2 + (size_t)(ns - 1) * B * 2 : nullptr;
     if (s == 1 && u8) {
       ICA_TRY(launch_pyramid_down(ctx, B, C, g[0].H, g[0].W, g[1].H, g[1].W, I1b, ctx->pyr1[1].as<float>(),
                                   ctx->mm_in.as<float>()));
-      ICA_TRY(launch_pyramid_down(ctx, B, C, g[0].H, g[0].W, g[1].H, g[1].W, I2b, ctx->pyr2[1].as<float>(), mm2));
+      ICA_TRY(launch_pyramid_down(ctx, B, C, g[0].H, g[0].W, g[1].H, g[1].W, I2b, ctx->pyr2[1].as<float>(), mm2, mm_next,
+                                  &have_coarsest));
     } else {
       ICA_TRY(launch_pyramid_down(ctx, B, C, g[s - 1].H, g[s - 1].W, g[s].H, g[s].W, L1[s - 1], ctx->pyr1[s].as<float>(),
                                   ctx->mm_in.as<float>()));
       ICA_TRY(launch_pyramid_down(ctx, B, C, g[s - 1].H, g[s - 1].W, g[s].H, g[s].W, L2[s - 1], ctx->pyr2[s].as<float>(),
-                                  mm2 + (size_t)(s - 1) * B * 2));
+                                  mm2 + (size_t)(s - 1) * B * 2, mm_next, &have_coarsest));
     }
     L1[s] = ctx->pyr1[s].as<float>();
     L2[s] = ctx->pyr2[s].as<float>();
   }
   if (ns == 1 && u8)
     ICA_TRY(launch_minmax(ctx, B, (size_t)C * g[0].H * g[0].W, I2b, mm2));
-  else
+  else if (!have_coarsest)
     ICA_TRY(launch_minmax(ctx, B, (size_t)C * g[ns - 1].H * g[ns - 1].W, L2[ns - 1], mm2 + (size_t)(ns - 1) * B * 2));
   if (ctx->board_dirty) ICA_HIP(ctx, hipStreamSynchronize(st));  // nothing may post to the board while it is reset
   for (size_t i = 0; i < (size_t)ns * std::max(1, max_iter); ++i) ctx->board[i] = -1;

@@ -555,6 +555,30 @@ __global__ __launch_bounds__(kBlock) void ica_minmax_final_kernel(const float* _
   }
 }
 
+// Range of a fused pyramid step's CLIPPED output from its tiles' unclipped ranges: clip(x, lo, hi) maps [a, b] to
+// [max(a, lo), min(b, hi)] (a <= hi and b >= lo always hold here: the operator reproduces constants).  One wave per pair.
+__global__ __launch_bounds__(kBlock) void ica_minmax_clipped_kernel(const float* __restrict__ part, int chunks, int batch,
+                                                                    const float* __restrict__ clip, float* __restrict__ out) {
+  const int b = blockIdx.x * kWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (b >= batch) return;  // whole wave
+  const float2* q = reinterpret_cast<const float2*>(part) + (size_t)b * chunks;
+  float lo = INFINITY, hi = -INFINITY;
+  for (int c = lane; c < chunks; c += 64) {
+    const float2 v = q[c];
+    lo = fminf(lo, v.x);
+    hi = fmaxf(hi, v.y);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    lo = fminf(lo, __shfl_down(lo, off, 64));
+    hi = fmaxf(hi, __shfl_down(hi, off, 64));
+  }
+  if (lane == 0) {
+    out[b * 2] = fminf(fmaxf(lo, clip[b * 2]), clip[b * 2 + 1]);
+    out[b * 2 + 1] = fminf(fmaxf(hi, clip[b * 2]), clip[b * 2 + 1]);
+  }
+}
+
 // ---- per-operator hooks -----------------------------------------------------------------------------
 __global__ void ica_gather_normal_equations_kernel(const double* partials, int tiles, int n, int batch, int have_b,
                                                    int have_h, const double* Hsetup_partials, double* Hout,
