@@ -364,10 +364,10 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? ICA_ITER_WAVES : U8 ? 3 : 4)) voi
     const int up = __shfl(plan_y, lane & 31, 64);  // lane 32 + c takes chunk c's word
     plan = lane < 32 ? plan_x : up;
   }
-  // Chunks by instruction stream (see the bands below): bit c of a mask = chunk c.  The tile is walked class by class --
-  // interior chunks, then masked-border ones, then the rest -- so that each loop contains ONE band: with two bands
-  // behind a branch in one loop the register allocator keeps the running sums in a second set of registers inside the
-  // straight-line band and copies them back at the back edge (17 + 17 instructions per band, 5 % of its issue time).
+  // Chunks by instruction stream (see the bands below): bit c of a mask = chunk c.  Kernels that accumulate the Hessian
+  // walk the tile class by class -- interior chunks, then masked-border ones, then the rest -- so that each loop contains
+  // ONE band: with two bands behind a branch in one loop the register allocator keeps the running sums in a second set of
+  // registers inside the straight-line band and copies them back at the back edge (17 + 17 instructions per band).
   unsigned cls_mask[3];
   {
     const bool mine = (lane < nchunks) & (lane < 32) & !(plan_x & (1 << 29));
@@ -539,6 +539,16 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? ICA_ITER_WAVES : U8 ? 3 : 4)) voi
       }
     }
   };
+  // Walking order.  Class by class (kH: 12-17 running sums, the copies of a one-loop walk cost 3 % of the kernel), or
+  // top to bottom in one loop (b only: a handful of sums, nothing to gain from separate loops -- and the out-of-order
+  // walk fetches more from HBM: neighbouring chunks share 9 of their 25 footprint rows and the column tiles next door
+  // walk the same rows at the same time; measured 1.26x against 1.06x the algorithmic bytes for affine L2 at 512^2,
+  // 1.14x against 1.08x for the robust homography kernel, which takes the trade for its 3 %).
+#ifdef ICA_WALK
+  constexpr int kWalk = ICA_WALK;
+#else
+  constexpr int kWalk = kH ? 0 : 1;
+#endif
   // first chunk of class >= c that is still to do, -1 if none (all wave-uniform)
   auto first_from = [&](int c) -> int {
     for (; c < 3; ++c)
@@ -547,7 +557,8 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? ICA_ITER_WAVES : U8 ? 3 : 4)) voi
   };
   int ring = 0;  // the float tile the next computed chunk sits in (two tiles: they alternate)
   {
-    const int k0 = first_from(0);
+    const unsigned all = cls_mask[0] | cls_mask[1] | cls_mask[2];
+    const int k0 = kWalk == 1 ? (all ? __builtin_ctz(all) : -1) : first_from(0);
     if (k0 >= 0 && ((U8 && w4) || (!U8 && NBUF == 2))) issue(k0, 0);
   }
   // one chunk: ring protocol, then the band of its class.  `next` = the chunk that follows in walking order (-1: none).
@@ -856,6 +867,12 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? ICA_ITER_WAVES : U8 ? 3 : 4)) voi
     {
       if constexpr (CLS == 0) band_fast(std::false_type{});
       else if constexpr (CLS == 1) band_fast(std::true_type{});
+      else if constexpr (CLS == 3) {  // (one loop, the class looked up per chunk)
+        if ((cls_mask[0] >> k) & 1) band_fast(std::false_type{});
+        else if ((cls_mask[1] >> k) & 1) band_fast(std::true_type{});
+        else if (staged) band_careful(std::true_type{});
+        else band_careful(std::false_type{});
+      }
       else if (staged) band_careful(std::true_type{});
       else band_careful(std::false_type{});
     }
@@ -863,20 +880,29 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? ICA_ITER_WAVES : U8 ? 3 : 4)) voi
   // Ring protocol (two tiles): chunk `next` is in flight while chunk k is computed.  A wave's copies retire in order;
   // the barrier makes every wave's part visible, and also means everyone has finished reading the chunk before k,
   // whose tile is the one `next` is about to overwrite.  Chunks that lie in the NaN frame entirely are in no class.
-  while (cls_mask[0]) {
-    const int k = __builtin_ctz(cls_mask[0]);
-    cls_mask[0] &= cls_mask[0] - 1;
-    step(IC<0>{}, k, first_from(0));
-  }
-  while (cls_mask[1]) {
-    const int k = __builtin_ctz(cls_mask[1]);
-    cls_mask[1] &= cls_mask[1] - 1;
-    step(IC<1>{}, k, first_from(1));
-  }
-  while (cls_mask[2]) {
-    const int k = __builtin_ctz(cls_mask[2]);
-    cls_mask[2] &= cls_mask[2] - 1;
-    step(IC<2>{}, k, first_from(2));
+  if constexpr (kWalk == 1) {  // top to bottom, one loop
+    unsigned rem = cls_mask[0] | cls_mask[1] | cls_mask[2];
+    while (rem) {
+      const int k = __builtin_ctz(rem);
+      rem &= rem - 1;
+      step(IC<3>{}, k, rem ? __builtin_ctz(rem) : -1);
+    }
+  } else {
+    while (cls_mask[0]) {
+      const int k = __builtin_ctz(cls_mask[0]);
+      cls_mask[0] &= cls_mask[0] - 1;
+      step(IC<0>{}, k, first_from(0));
+    }
+    while (cls_mask[1]) {
+      const int k = __builtin_ctz(cls_mask[1]);
+      cls_mask[1] &= cls_mask[1] - 1;
+      step(IC<1>{}, k, first_from(1));
+    }
+    while (cls_mask[2]) {
+      const int k = __builtin_ctz(cls_mask[2]);
+      cls_mask[2] &= cls_mask[2] - 1;
+      step(IC<2>{}, k, first_from(2));
+    }
   }
   // The y-moments of one lane's column over the whole tile (<= 64 rows per lane) stay in fp32 registers; they are
   // promoted to fp64 here, before x powers up to x^4 are applied and 64 lanes x 4 waves x tiles are summed.
