@@ -442,16 +442,21 @@ void launch_accumulate_mode(const ica_ctx* ctx, int mode, int tt, int C, dim3 gr
 // spin, then sched_yield, then 50 us sleeps -- a waiting context does not hold a core -- under a wall-clock limit.
 // Returns the count, or -1 on timeout.
 int wait_board(volatile int* slot, double timeout_s) {
+  // The count is posted when the previous iteration's kernel STARTS, i.e. normally long before it is asked for; when
+  // it is not there yet, the kernel in front of it is still running (at most a few milliseconds).  Poll for up to 4 ms
+  // (yielding the core between bursts of reads), and only then go to sleep between polls: a sleeping waiter wakes
+  // 50-100 us late, which showed as five ~40 us holes per solve of configs[1].
   int v = *slot;
-  for (int i = 0; v < 0 && i < 4000; ++i) v = *slot;
   if (v >= 0) return v;
   const auto t0 = std::chrono::steady_clock::now();
-  for (unsigned n = 0; (v = *slot) < 0; ++n) {
-    if (n < 200) sched_yield();
+  for (unsigned n = 0;; ++n) {
+    for (int i = 0; i < 64 && (v = *slot) < 0; ++i) {}
+    if (v >= 0) return v;
+    const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (waited > timeout_s) return v;
+    if (waited < 4e-3) sched_yield();
     else std::this_thread::sleep_for(std::chrono::microseconds(50));
-    if ((n & 15) == 15 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) break;
   }
-  return v;
 }
 
 template <class TIn>
