@@ -29,5 +29,5 @@ for r in st:
     per[n][0] += 1; per[n][1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
 for n, (c, t) in sorted(per.items(), key=lambda kv: -kv[1][1]): print(f"  {n:<36} x{c:<4} {t/1e3:8.1f} us")
 if len(sys.argv) > 2:
-    print("accumulate launches (us):", " ".join(f"{(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3:.0f}" for r in st if "accumulate2" in r["Kernel_Name"]))
-    print("grid sizes:", " ".join(r.get("Grid_Size_X", r.get("Grid_Size", "?")) for r in st if "accumulate2" in r["Kernel_Name"]))
+    print("accumulate launches (us):", " ".join(f"{(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3:.0f}" for r in st if ("accumulate2" in r["Kernel_Name"] or "iterate" in r["Kernel_Name"])))
+    print("grid sizes:", " ".join(r.get("Grid_Size_X", r.get("Grid_Size", "?")) for r in st if ("accumulate2" in r["Kernel_Name"] or "iterate" in r["Kernel_Name"])))
