@@ -236,6 +236,31 @@ def test_pyramid_down_single_kernel(eng, eng_two_pass, shape, C, nu):
     assert clipped > 0  # the saturated image does get clipped
 
 
+def test_pyramid_down_single_kernel_random_shapes(eng, eng_two_pass):
+    """Seeded sweep of shapes for the one-kernel pyramid step against the two-kernel step (bit for bit): heights from 1
+    row up, widths from 4 columns (a single, mostly empty column block) to several blocks, batches of 1-3 images with 1-3
+    channels, three factors.  The two-kernel step itself is pinned to the restated skimage.rescale by the tests above."""
+    rng = np.random.default_rng(20261005)
+    for case in range(40):
+        H_ = int(rng.integers(1, 220))
+        W_ = 4 * int(rng.integers(1, 280))
+        C = int(rng.integers(1, 4))
+        nu = [0.5, 0.5, 0.75, 0.3][case % 4]
+        nimg = int(rng.integers(1, 4))
+        if H_ * W_ * C * nimg > 600000:
+            H_ = max(1, 600000 // (W_ * C * nimg))
+        imgs = [np.round(rng.uniform(0, 255, (H_, W_, C))) for _ in range(nimg)]
+        for im in imgs:  # flat saturated patches: the clip is active somewhere
+            im[: max(1, H_ // 3), : max(1, W_ // 4)] = 255.0
+            im[H_ // 2:, W_ // 2:] = 0.0
+        got = to_np(eng.pyramid_down(to_dev(eng, *imgs), nu))
+        two = to_np(eng_two_pass.pyramid_down(to_dev(eng_two_pass, *imgs), nu))
+        assert len(got) == len(two) == nimg
+        for i in range(nimg):
+            assert got[i].shape == two[i].shape, (case, H_, W_, C, nu)
+            np.testing.assert_array_equal(got[i], two[i], err_msg=str((case, H_, W_, C, nu)))
+
+
 @pytest.mark.parametrize("nu", [0.1, 0.07])
 def test_pyramid_down_very_small_factor(eng, nu):
     """The reference accepts any nu; factors below ~0.12 exceed what the tiled passes are sized for and run the generic
