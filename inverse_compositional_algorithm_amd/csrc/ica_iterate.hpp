@@ -40,6 +40,9 @@
 #ifndef ICA_ITER_WAVES
 #define ICA_ITER_WAVES 6
 #endif
+#ifndef ICA_ITER_WAVES_U8   // waves per SIMD asked of the uint8-storage kernel (its 19.9 KB of LDS would allow 8)
+#define ICA_ITER_WAVES_U8 ICA_ITER_WAVES
+#endif
 #ifndef ICA_ROW_FENCE
 #define ICA_ROW_FENCE 1
 #endif
@@ -190,7 +193,7 @@ __device__ __forceinline__ float rho_prime_t(float t2, float lam2) {
 // workgroup: barrier, expand chunk k, barrier, start the copy of chunk k+1, compute chunk k.
 template <int TT, int MODE, int C, int RT, bool U8>
 // (second launch bound = waves per SIMD the register allocator must leave room for: what the LDS footprint allows)
-__global__ __launch_bounds__(kBlock, (C == 1 ? ICA_ITER_WAVES : U8 ? 3 : 4)) void ica_iterate_kernel(LevelArgs a) {
+__global__ __launch_bounds__(kBlock, (C == 1 ? (U8 ? ICA_ITER_WAVES_U8 : ICA_ITER_WAVES) : U8 ? 3 : 4)) void ica_iterate_kernel(LevelArgs a) {
   using TIn = std::conditional_t<U8, unsigned char, float>;
   constexpr int ES = (int)sizeof(TIn);    // bytes per image element in HBM
   constexpr int N = NP<TT>::n;
