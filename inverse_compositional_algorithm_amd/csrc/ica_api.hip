@@ -142,12 +142,16 @@ int validate(const ica_problem* pr) {
 // Tile height for a launch over `pairs` pairs: the tallest tile (taller tiles amortise the per-tile fold) that still
 // gives the launch >= ~4 workgroups per CU.  Late iterations, when only a few pairs are still iterating, therefore
 // use short tiles and spread those pairs over the whole chip instead of running 16 long workgroups per pair.
+#ifndef ICA_MIN_TH
+#define ICA_MIN_TH 16
+#endif
 void set_tiling(LevelGeom& g, int pairs, int max_tile_h) {
   g.tiles_x = (g.W + kTileW - 1) / kTileW;
-  int th = std::max(16, std::min(512, max_tile_h));   // (at most 32 chunks of 16 rows per tile: the chunk plans of a tile live in one register)
-  while (th > 16) {
+  // (at most 32 chunks of 16 or 32 rows per tile: the chunk plans of a tile live in one register)
+  int th = std::max(ICA_MIN_TH, std::min(512, max_tile_h));
+  while (th > ICA_MIN_TH) {
     const long blocks = (long)pairs * g.tiles_x * ((g.H + th - 1) / th);
-    if (blocks >= 2048 && th <= std::max(16, g.H)) break;
+    if (blocks >= 2048 && th <= std::max(ICA_MIN_TH, g.H)) break;
     th >>= 1;
   }
   g.tile_h = th;

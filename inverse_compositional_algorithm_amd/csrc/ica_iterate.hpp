@@ -40,20 +40,20 @@
 #ifndef ICA_ITER_WAVES
 #define ICA_ITER_WAVES 6
 #endif
-#ifndef ICA_ITER_WAVES_U8   // waves per SIMD asked of the uint8-storage kernel (its 19.9 KB of LDS would allow 8)
-#define ICA_ITER_WAVES_U8 ICA_ITER_WAVES
+#ifndef ICA_ITER_WAVES_U8   // waves per SIMD asked of the one-channel uint8-storage kernel (28.6 KB of LDS: 5 workgroups per CU)
+#define ICA_ITER_WAVES_U8 5
 #endif
 #ifndef ICA_ROW_FENCE
 #define ICA_ROW_FENCE 1
 #endif
-#ifndef ICA_NBUF
-#define ICA_NBUF 2
+#ifndef ICA_NBUF   // float tiles per workgroup for one channel (2: chunk k+1 copied under chunk k's arithmetic)
+#define ICA_NBUF 1
 #endif
-#ifndef ICA_CH
-#define ICA_CH 16
+#ifndef ICA_CH     // image rows per chunk, one channel
+#define ICA_CH 32
 #endif
-#ifndef ICA_R2
-#define ICA_R2 (ICA_CH + 9)
+#ifndef ICA_CH3    // image rows per chunk, three channels (a 32-row tile of three channels does not fit the LDS)
+#define ICA_CH3 16
 #endif
 
 #include "ica_common.hpp"
@@ -103,12 +103,18 @@ template <int TT> struct MomLayout {
 };
 
 template <int C> struct TileCfg {
-  static constexpr int ch = ICA_CH;                    // image rows per chunk: 4 waves x ch/4 rows
+  // Image rows per chunk: 4 waves x ch/4 rows.  One channel: 32 rows in ONE 22.9 KB tile (6 workgroups per CU), copy and
+  // arithmetic of a workgroup alternate and the other five overlap them.  Measured against 16-row chunks in two tiles
+  // (chunk k+1 copied under chunk k's arithmetic, 26.4 KB): 3-7 % faster on every one-channel kernel -- half the
+  // workgroup barriers and copy set-ups per row, 41 instead of 50 footprint rows fetched per 32 rows of output -- where
+  // more waves, more buffers or fewer instructions had bought nothing (profiles/r02_ablation.txt).  The uint8 kernel
+  // uses the same chunk (bit-identical results need the same rows in the same waves); with its staging area it holds
+  // 28.6 KB, 5 workgroups per CU, and is still 4 % faster than with 16-row chunks.
+  // Three channels: 16 rows, one 39.5 KB tile, 4 workgroups per CU.
+  static constexpr int ch = (C == 1) ? ICA_CH : ICA_CH3;
   static constexpr int rw = ch / kWaves;
-  static constexpr int p2 = 80, r2 = ICA_R2;           // I2 footprint buffer: pitch (floats) x rows
+  static constexpr int p2 = 80, r2 = ch + 9;           // I2 footprint buffer: pitch (floats) x rows
   static constexpr int p1 = 72, r1 = ch + 2;           // I1 buffer: columns x_t0-4 .. x_t0+67, rows yc0-1 .. yc0+ch
-  // C == 1: two buffers (26 KB -> 6 workgroups per CU): chunk k is computed while k+1 is in flight.
-  // C == 3: one buffer (40.5 KB), copy and arithmetic of one workgroup alternate, 3 workgroups overlap.
   static constexpr int nbuf = (C == 1) ? ICA_NBUF : 1;
   static constexpr int buf_floats = C * (p2 * r2 + p1 * r1);
 };
