@@ -755,7 +755,8 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? (U8 ? ICA_ITER_WAVES_U8 : ICA_ITE
         if constexpr (MASKED && kH) w = live ? w : 0.0f;  // pixels in the NaN frame contribute nothing (derivatives.py:84)
         accumulate(w, ix2, iy2, di, yf);
 #if ICA_ROW_FENCE
-        __builtin_amdgcn_sched_barrier(0);  // keep the rows apart: a row hoisted over the previous one's sums costs registers
+        // keep the rows apart: a row hoisted over the previous one's sums costs registers
+        if ((i + 1) % ICA_ROW_FENCE == 0) __builtin_amdgcn_sched_barrier(0);
 #endif
       }
     };
