@@ -145,13 +145,16 @@ int validate(const ica_problem* pr) {
 #ifndef ICA_MIN_TH
 #define ICA_MIN_TH 16
 #endif
+#ifndef ICA_MIN_BLOCKS   // a launch is cut into shorter tiles until it has this many workgroups (1536 are resident)
+#define ICA_MIN_BLOCKS 2048
+#endif
 void set_tiling(LevelGeom& g, int pairs, int max_tile_h) {
   g.tiles_x = (g.W + kTileW - 1) / kTileW;
   // (at most 32 chunks of 16 or 32 rows per tile: the chunk plans of a tile live in one register)
   int th = std::max(ICA_MIN_TH, std::min(512, max_tile_h));
   while (th > ICA_MIN_TH) {
     const long blocks = (long)pairs * g.tiles_x * ((g.H + th - 1) / th);
-    if (blocks >= 2048 && th <= std::max(ICA_MIN_TH, g.H)) break;
+    if (blocks >= ICA_MIN_BLOCKS && th <= std::max(ICA_MIN_TH, g.H)) break;
     th >>= 1;
   }
   g.tile_h = th;
