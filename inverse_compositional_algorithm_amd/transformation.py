@@ -45,6 +45,23 @@ def params2matrix(p, transform_type) -> np.ndarray:
     return m
 
 
+_TYPE_OF_NPARAMS = {2: 1, 3: 2, 4: 3, 6: 4, 8: 5}
+
+
+def project(x, y, p, nparams):
+    """reference: transformation.py:144-185 -- the point (x, y) under the transform whose type is given by its NUMBER of
+    parameters (2, 3, 4, 6 or 8); anything else raises the reference's ValueError.  Scalars or arrays."""
+    if nparams not in _TYPE_OF_NPARAMS:
+        raise ValueError("Invalid transformation type")
+    m = params2matrix(p, _TYPE_OF_NPARAMS[nparams])
+    xp = m[0, 0] * x + m[0, 1] * y + m[0, 2]
+    yp = m[1, 0] * x + m[1, 1] * y + m[1, 2]
+    if nparams == 8:
+        d = m[2, 0] * x + m[2, 1] * y + 1
+        return xp / d, yp / d
+    return xp, yp
+
+
 def matrix2params(matrix, transform_type):
     """reference: transformation.py:238-263 (returns a list, as the reference does)."""
     t = _tt(transform_type)

@@ -91,3 +91,19 @@ def test_synthetic_generator_is_deterministic():
     b = syn.make_pair(5, 64, 80, 3, 5, robust_clutter=True)
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
     assert a[0].dtype == np.float32 and a[0].min() >= 0 and a[0].max() <= 255 and np.all(a[0] == np.round(a[0]))
+
+
+def test_project_is_the_matrix_action():
+    """transformation.project (ref transformation.py:144-185): the type is given by the number of parameters."""
+    from inverse_compositional_algorithm_amd import transformation as tr
+    rng = np.random.default_rng(5)
+    x, y = rng.uniform(0, 300, 9), rng.uniform(0, 200, 9)
+    for t, n in ((1, 2), (2, 3), (3, 4), (4, 6), (5, 8)):
+        p = rng.normal(size=n) * (1e-3 if t == 5 else 0.1)
+        M = tr.params2matrix(p, t)
+        h = M @ np.stack([x, y, np.ones_like(x)])
+        gx, gy = tr.project(x, y, p, n)
+        np.testing.assert_allclose(gx, h[0] / h[2], rtol=1e-13)
+        np.testing.assert_allclose(gy, h[1] / h[2], rtol=1e-13)
+    with pytest.raises(ValueError, match="Invalid transformation type"):
+        tr.project(1.0, 2.0, np.zeros(5), 5)
