@@ -197,6 +197,33 @@ int ica_op_pyramid_down_dev(ica_ctx* ctx, int batch, int channels, int height, i
 int ica_op_zoom_in_parameters_dev(ica_ctx* ctx, int batch, int transform_type, int w, int h, int ww,
                                   int hh, double* p_inout);
 
+/* ---- the reference's per-operator ARRAY functions in their own shapes -------------------------------------------
+ * float64, channel-last, materialised tensors -- what the fused iteration kernel never builds.  They exist so that code
+ * written against the reference's operator functions (its unit tests test/test_derivatives.py, the profiling notebook)
+ * runs against this library; `derivatives.py` / `image_optimisation.py` of the Python package call them.
+ * nparams is the LAST dimension of DIJ (1..8, not tied to a transform type, as in the reference). */
+
+/* derivatives.py:7-70 jacobian(transform_type, nx, ny) -> J [ny][nx][2 * nparams]. */
+int ica_op_ref_jacobian_dev(ica_ctx* ctx, int transform_type, int nx, int ny, double* J_out);
+
+/* image_optimisation.py:159-200 steepest_descent_images(Ix, Iy, J, nparams): Ix, Iy [ny][nx][nz], J [ny][nx][2n]
+ * -> DIJ [ny][nx][nz][n]. */
+int ica_op_ref_steepest_descent_dev(ica_ctx* ctx, int ny, int nx, int nz, int nparams, const double* Ix,
+                                    const double* Iy, const double* J, double* DIJ_out);
+
+/* derivatives.py:73-107 hessian / hessian_robust and image_optimisation.py:82-143 independent_vector(_robust):
+ * H = sum rho * DIJ^T DIJ ([n][n]), b = sum rho * DIJ^T DI ([n]); non-finite entries of DIJ / DI count as zero.
+ * DI, rho ([ny][nx]), H_out, b_out are nullable (rho NULL = weights 1; b_out requires DI). */
+int ica_op_ref_normal_dev(ica_ctx* ctx, int ny, int nx, int nz, int nparams, const double* DIJ, const double* DI,
+                          const double* rho, double* H_out, double* b_out);
+
+/* image_optimisation.py:16-53 rhop(t2, lambda, type), element-wise over `count` values. */
+int ica_op_ref_rhop_dev(ica_ctx* ctx, size_t count, const double* t2, double lambda, int robust_type, double* out);
+
+/* image_optimisation.py:56-78 robust_error_function(DI [ny][nx][nz], lambda, type) -> rho [ny][nx]. */
+int ica_op_ref_robust_error_dev(ica_ctx* ctx, int ny, int nx, int nz, const double* DI, double lambda,
+                                int robust_type, double* rho_out);
+
 /* transformation.py:266-318 transform_image (the reference's test-data generator): out = bilinear I(M.x) with
  * skimage.transform.warp(image, tform.inverse, preserve_range=True) semantics (order 1, mode constant, cval 0: a tap
  * outside the image contributes 0; clipped to the input range).  M is [B][9], row-major 3x3, the matrix that maps

@@ -60,6 +60,11 @@ _SIGNATURES = {
     "ica_op_pyramid_down_dev": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _P, _P]),
     "ica_op_zoom_in_parameters_dev": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "ica_op_transform_image_dev": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    "ica_op_ref_jacobian_dev": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
+    "ica_op_ref_steepest_descent_dev": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "ica_op_ref_normal_dev": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
+    "ica_op_ref_rhop_dev": (C.c_int, [_P, C.c_size_t, _P, C.c_double, C.c_int, _P]),
+    "ica_op_ref_robust_error_dev": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_double, C.c_int, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

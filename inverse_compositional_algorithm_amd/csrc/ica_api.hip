@@ -17,6 +17,7 @@
 
 #include "../../include/ica_hip.h"
 #include "ica_kernels.hpp"
+#include "ica_refops.hpp"
 #include "ica_iterate_launch.hpp"
 #include "ica_pyramid.hpp"
 
@@ -82,7 +83,7 @@ struct ica_ctx {
   DevBuf pyr1[ICA_MAX_SCALES], pyr2[ICA_MAX_SCALES];  // levels >= 1
   DevBuf tmp_resample;                                // intermediate of the separable pyramid pass
   DevBuf partials, hinv, p_prev, lambda_it, error, niter, lists, counts, count_hist, minmax, mm_part, mm_in, out_part;
-  DevBuf scratch_p;
+  DevBuf scratch_p, ref_part;
   int* pinned_count = nullptr;   // one list's shard counters for synchronous reads + a [scales][max_iter] board the kernels post to
   int* board = nullptr;          // host pointer of the board (pinned, host-coherent)
   int* board_dev = nullptr;      // device pointer of the same memory
@@ -99,7 +100,7 @@ struct ica_ctx {
     if (handover) (void)hipEventDestroy(handover);
     for (int i = 0; i < ICA_MAX_SCALES; ++i) { pyr1[i].release(); pyr2[i].release(); }
     DevBuf* all[] = {&tmp_resample, &partials, &hinv, &p_prev, &lambda_it, &error, &niter, &lists, &counts,
-                     &count_hist, &minmax, &mm_part, &mm_in, &out_part, &scratch_p};
+                     &count_hist, &minmax, &mm_part, &mm_in, &out_part, &scratch_p, &ref_part};
     for (auto* b : all) b->release();
     if (pinned_count) (void)hipHostFree(pinned_count);
     if (board) (void)hipHostFree(board);
@@ -966,6 +967,86 @@ int ica_op_pyramid_down_dev(ica_ctx* ctx, int batch, int channels, int height, i
   const int w = std::max(1, round_half_even(width * nu)), h = std::max(1, round_half_even(height * nu));
   ICA_HIP(ctx, ctx->mm_in.ensure((size_t)batch * 2 * sizeof(float)));
   return launch_pyramid_down(ctx, batch, channels, height, width, h, w, in, out, ctx->mm_in.as<float>());
+}
+
+int ica_op_ref_jacobian_dev(ica_ctx* ctx, int tt, int nx, int ny, double* J) {
+  if (!ctx || !J || nx < 0 || ny < 0) return ICA_EINVAL_ARG;
+  const int n = nparams_of(tt);
+  if (n < 0) return ICA_EINVAL_TRANSFORM;
+  const size_t px = (size_t)nx * ny;
+  if (px == 0) return ICA_OK;
+  ICA_HIP(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(ica_ref_jacobian_kernel, dim3((unsigned)((px + kRefBlock - 1) / kRefBlock)), dim3(kRefBlock), 0, ctx->stream,
+                     tt, n, nx, ny, J);
+  ICA_HIP(ctx, hipGetLastError());
+  return ICA_OK;
+}
+
+int ica_op_ref_steepest_descent_dev(ica_ctx* ctx, int ny, int nx, int nz, int n, const double* Ix, const double* Iy,
+                                    const double* J, double* DIJ) {
+  if (!ctx || ny < 0 || nx < 0 || nz < 0 || n < 1 || n > kRefMaxN) return ICA_EINVAL_ARG;
+  const size_t total = (size_t)ny * nx * nz * n;
+  if (total == 0) return ICA_OK;
+  if (!Ix || !Iy || !J || !DIJ) return ICA_EINVAL_ARG;
+  ICA_HIP(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(ica_ref_sd_images_kernel, dim3((unsigned)((total + kRefBlock - 1) / kRefBlock)), dim3(kRefBlock), 0,
+                     ctx->stream, (size_t)ny * nx, nz, n, Ix, Iy, J, DIJ);
+  ICA_HIP(ctx, hipGetLastError());
+  return ICA_OK;
+}
+
+int ica_op_ref_normal_dev(ica_ctx* ctx, int ny, int nx, int nz, int n, const double* DIJ, const double* DI, const double* rho,
+                          double* H, double* b) {
+  if (!ctx || ny < 0 || nx < 0 || nz < 0 || n < 1 || n > kRefMaxN || (b && !DI)) return ICA_EINVAL_ARG;
+  ICA_HIP(ctx, hipSetDevice(ctx->device));
+  if (H) ICA_HIP(ctx, hipMemsetAsync(H, 0, (size_t)n * n * sizeof(double), ctx->stream));
+  if (b) ICA_HIP(ctx, hipMemsetAsync(b, 0, (size_t)n * sizeof(double), ctx->stream));
+  const size_t px = (size_t)ny * nx;
+  if (px == 0 || nz == 0 || (!H && !b)) return ICA_OK;
+  if (!DIJ) return ICA_EINVAL_ARG;
+  const int blocks = (int)std::min<size_t>(kRefBlocks, (px + kRefBlock - 1) / kRefBlock);
+  ICA_HIP(ctx, ctx->ref_part.ensure((size_t)blocks * kRefAcc * sizeof(double)));
+  double* part = ctx->ref_part.as<double>();
+#define ICA_REF_CASE(NN)                                                                                              \
+  case NN:                                                                                                            \
+    hipLaunchKernelGGL(ica_ref_normal_partial_kernel<NN>, dim3(blocks), dim3(kRefBlock), 0, ctx->stream, px, nz, DIJ, DI, rho, \
+                       part);                                                                                         \
+    hipLaunchKernelGGL(ica_ref_normal_final_kernel<NN>, dim3(1), dim3(64), 0, ctx->stream, blocks, part, H, b);        \
+    break;
+  switch (n) {
+    ICA_REF_CASE(1) ICA_REF_CASE(2) ICA_REF_CASE(3) ICA_REF_CASE(4) ICA_REF_CASE(5) ICA_REF_CASE(6) ICA_REF_CASE(7)
+    ICA_REF_CASE(8)
+    default: break;
+  }
+#undef ICA_REF_CASE
+  ICA_HIP(ctx, hipGetLastError());
+  return ICA_OK;
+}
+
+int ica_op_ref_rhop_dev(ica_ctx* ctx, size_t count, const double* t2, double lambda, int robust_type, double* out) {
+  if (!ctx) return ICA_EINVAL_ARG;
+  if (robust_type < ICA_QUADRATIC || robust_type > ICA_CHARBONNIER) return ICA_EINVAL_ROBUST;
+  if (count == 0) return ICA_OK;
+  if (!t2 || !out) return ICA_EINVAL_ARG;
+  ICA_HIP(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(ica_ref_rhop_kernel, dim3((unsigned)((count + kRefBlock - 1) / kRefBlock)), dim3(kRefBlock), 0, ctx->stream,
+                     count, t2, lambda, robust_type, out);
+  ICA_HIP(ctx, hipGetLastError());
+  return ICA_OK;
+}
+
+int ica_op_ref_robust_error_dev(ica_ctx* ctx, int ny, int nx, int nz, const double* DI, double lambda, int robust_type,
+                                double* rho) {
+  if (!ctx || ny < 0 || nx < 0 || nz < 0) return ICA_EINVAL_ARG;
+  if (robust_type < ICA_QUADRATIC || robust_type > ICA_CHARBONNIER) return ICA_EINVAL_ROBUST;
+  const size_t px = (size_t)ny * nx;
+  if (px == 0) return ICA_OK;
+  if (!rho || (nz > 0 && !DI)) return ICA_EINVAL_ARG;
+  ICA_HIP(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(ica_ref_robust_error_kernel, dim3((unsigned)((px + kRefBlock - 1) / kRefBlock)), dim3(kRefBlock), 0,
+                     ctx->stream, px, nz, DI, lambda, robust_type, rho);
+  ICA_HIP(ctx, hipGetLastError());
+  return ICA_OK;
 }
 
 int ica_op_zoom_in_parameters_dev(ica_ctx* ctx, int batch, int tt, int w, int h, int ww, int hh, double* p) {

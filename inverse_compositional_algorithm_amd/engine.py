@@ -196,6 +196,60 @@ class IcaEngine:
         check(self.lib.ica_op_pyramid_down_dev(self.ctx, B, Cc, H, W, float(nu), _ptr(I), _ptr(out)), self.ctx)
         return out
 
+    # ---- the reference's per-operator array functions (float64, channel-last; include/ica_hip.h "ica_op_ref_*") ----
+    def _f64(self, a) -> torch.Tensor:
+        import numpy as np
+        return torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float64))).to(self.device)
+
+    def ref_jacobian(self, transform_type: int, nx: int, ny: int):
+        n = self.lib.ica_nparams(int(transform_type))
+        if n < 0:
+            raise ValueError("Unknown transform type")
+        J = torch.zeros(int(ny), int(nx), 2 * n, dtype=torch.float64, device=self.device)
+        self._bind_stream()
+        check(self.lib.ica_op_ref_jacobian_dev(self.ctx, int(transform_type), int(nx), int(ny), _ptr(J)), self.ctx)
+        return J.cpu().numpy()
+
+    def ref_steepest_descent(self, Ix, Iy, J, nparams: int):
+        ny, nx, nz = Ix.shape
+        DIJ = torch.zeros(ny, nx, nz, int(nparams), dtype=torch.float64, device=self.device)
+        a, b, c = self._f64(Ix), self._f64(Iy), self._f64(J)
+        self._bind_stream()
+        check(self.lib.ica_op_ref_steepest_descent_dev(self.ctx, ny, nx, nz, int(nparams), _ptr(a), _ptr(b), _ptr(c), _ptr(DIJ)),
+              self.ctx)
+        return DIJ.cpu().numpy()
+
+    def ref_normal(self, DIJ, DI=None, rho=None, want_h=True, want_b=False):
+        ny, nx, nz, n = DIJ.shape
+        d = self._f64(DIJ)
+        di = self._f64(DI) if DI is not None else None
+        r = self._f64(rho) if rho is not None else None
+        H = torch.zeros(n, n, dtype=torch.float64, device=self.device) if want_h else None
+        b = torch.zeros(n, dtype=torch.float64, device=self.device) if want_b else None
+        if n > 0:
+            self._bind_stream()
+            check(self.lib.ica_op_ref_normal_dev(self.ctx, ny, nx, nz, n, _ptr(d), _ptr(di) if di is not None else None,
+                                                 _ptr(r) if r is not None else None, _ptr(H) if want_h else None,
+                                                 _ptr(b) if want_b else None), self.ctx)
+        return (H.cpu().numpy() if want_h else None), (b.cpu().numpy() if want_b else None)
+
+    def ref_rhop(self, t2, lambda_: float, robust_type: int):
+        import numpy as np
+        t = self._f64(np.atleast_1d(t2))
+        out = torch.empty_like(t)
+        self._bind_stream()
+        check(self.lib.ica_op_ref_rhop_dev(self.ctx, t.numel(), _ptr(t), float(lambda_), int(robust_type), _ptr(out)), self.ctx)
+        return out.cpu().numpy().reshape(np.shape(t2))
+
+    def ref_robust_error(self, DI, lambda_: float, robust_type: int):
+        ny, nx, nz = DI.shape
+        d = self._f64(DI)
+        rho = torch.zeros(ny, nx, dtype=torch.float64, device=self.device)
+        self._bind_stream()
+        check(self.lib.ica_op_ref_robust_error_dev(self.ctx, ny, nx, nz, _ptr(d), float(lambda_), int(robust_type), _ptr(rho)),
+              self.ctx)
+        return rho.cpu().numpy()
+
     def zoom_in_parameters(self, p, transform_type: int, w: int, h: int, ww: int, hh: int):
         B = p.shape[0]
         p = self._params(p, B).clone()

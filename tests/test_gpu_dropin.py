@@ -173,3 +173,81 @@ def test_bicubic_interpolation_module_matches_oracle_warp():
         assert got.shape == want.shape and got.dtype == np.float64
         assert np.array_equal(np.isnan(got), np.isnan(want))
         np.testing.assert_allclose(np.nan_to_num(got), np.nan_to_num(want), atol=2e-3)
+
+
+# ---- the reference's per-operator array functions (derivatives.py, image_optimisation.py) on the GPU ----------------
+def test_operator_functions_reference_unit_test_tables():
+    """The known answers of the reference's own unit tests (test/test_derivatives.py:11-101), through the drop-in
+    `derivatives` module: 2x2-grid Jacobians, hessian of a random (3,3,4,2) DIJ incl. NaN / inf entries, empty DIJ."""
+    from inverse_compositional_algorithm_amd import derivatives as de
+    J = de.jacobian(T.TRANSLATION, 2, 2)
+    assert J.shape == (2, 2, 4) and J.dtype == np.float64
+    np.testing.assert_array_equal(J[0, 1], [1, 0, 0, 1])
+    np.testing.assert_array_equal(de.jacobian(T.EUCLIDEAN, 2, 2)[1, 1], [1, 0, -1, 0, 1, 1])
+    np.testing.assert_array_equal(de.jacobian(T.SIMILARITY, 2, 2)[1, 0], [1, 0, 0, -1, 0, 1, 1, 0])
+    np.testing.assert_array_equal(de.jacobian(T.AFFINITY, 2, 2),
+                                  [[[1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0], [1, 0, 1, 0, 0, 0, 0, 1, 0, 0, 1, 0]],
+                                   [[1, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1], [1, 0, 1, 1, 0, 0, 0, 1, 0, 0, 1, 1]]])
+    rng = np.random.default_rng(0)
+    DIJ = rng.random((3, 3, 4, 2))
+    want = sum(DIJ[i, j].T @ DIJ[i, j] for i in range(3) for j in range(3))
+    np.testing.assert_allclose(de.hessian(DIJ), want, rtol=1e-13)
+    DIJ[0, 0, 0, 0] = np.nan
+    DIJ[1, 1, 1, 1] = np.inf
+    np.testing.assert_allclose(de.hessian(DIJ), oc.hessian(DIJ), rtol=1e-13)   # element-wise zero fill, as implemented
+    H0 = de.hessian(np.zeros((0, 0, 0, 0)))
+    assert H0.shape == (0, 0)
+
+
+@pytest.mark.parametrize("t", [T.TRANSLATION, T.EUCLIDEAN, T.SIMILARITY, T.AFFINITY, T.HOMOGRAPHY])
+def test_operator_functions_match_oracle(t):
+    """jacobian -> steepest_descent_images -> hessian(_robust) / independent_vector(_robust) -> inverse -> solve, every
+    step against the oracle's restatement of the same reference function (itself pinned to the reference)."""
+    from inverse_compositional_algorithm_amd import derivatives as de
+    from inverse_compositional_algorithm_amd import image_optimisation as io
+    rng = np.random.default_rng(100 + t.value)
+    ny, nx, nz, n = 37, 53, 3, t.nparams()
+    J = de.jacobian(t, nx, ny)
+    np.testing.assert_array_equal(J, oc.jacobian(t.value, nx, ny))
+    Ix, Iy = rng.normal(size=(ny, nx, nz)), rng.normal(size=(ny, nx, nz))
+    Ix[3, 4, 1] = np.nan
+    DIJ = io.steepest_descent_images(Ix, Iy, J, n)
+    want_DIJ = oc.steepest_descent_images(Ix, Iy, J, n)
+    np.testing.assert_array_equal(np.isnan(DIJ), np.isnan(want_DIJ))
+    np.testing.assert_allclose(np.nan_to_num(DIJ), np.nan_to_num(want_DIJ), rtol=1e-15, atol=0)
+    DI = rng.normal(size=(ny, nx, nz)) * 20
+    DI[5, 6] = np.nan
+    DI[7, 8, 2] = np.inf
+    for r in (R.QUADRATIC, R.TRUNCATED_QUADRATIC, R.GERMAN_MCCLURE, R.LORENTZIAN, R.CHARBONNIER):
+        rho = io.robust_error_function(DI, 7.5, r)
+        np.testing.assert_allclose(rho, oc.robust_error_function(DI, 7.5, r.value), rtol=1e-14)
+    t2 = rng.uniform(0, 400, (5, 7))
+    np.testing.assert_allclose(io.rhop(t2, 3.0, R.LORENTZIAN), oc.rhop(t2, 3.0, oc.LORENTZIAN), rtol=1e-15)
+    np.testing.assert_allclose(io.rhop(t2, 3.0, R.CHARBONNIER), oc.rhop(t2, 3.0, oc.CHARBONNIER), rtol=1e-15)
+    rho = io.robust_error_function(DI, 7.5, R.LORENTZIAN)
+    H = de.hessian(DIJ)
+    Hr = de.hessian_robust(DIJ, rho, n)
+    b = io.independent_vector(DIJ, DI, n)
+    br = io.independent_vector_robust(DIJ, DI, rho, n)
+    sc = np.sqrt(np.abs(np.diag(oc.hessian(want_DIJ)))) + 1e-300
+    np.testing.assert_allclose(H / np.outer(sc, sc), oc.hessian(want_DIJ) / np.outer(sc, sc), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(Hr / np.outer(sc, sc), oc.hessian(want_DIJ, rho) / np.outer(sc, sc), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(b / sc, oc.independent_vector(want_DIJ, DI) / sc, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(br / sc, oc.independent_vector(want_DIJ, DI, rho) / sc, rtol=0, atol=1e-9)
+    assert H.shape == (n, n) and b.shape == (n,)
+    H1 = de.inverse_hessian(H, n)
+    np.testing.assert_array_equal(H1, oc.inverse_hessian(H))
+    err, dp = io.parametric_solve(H1, b, n)
+    e_w, dp_w = oc.parametric_solve(H1, b)
+    assert err == e_w and np.array_equal(dp, dp_w)
+    np.testing.assert_array_equal(de.inverse_hessian(np.zeros((n, n)), n), np.zeros((n, n)))
+
+
+def test_operator_functions_error_behaviour():
+    from inverse_compositional_algorithm_amd import image_optimisation as io
+    with pytest.raises(ValueError, match="Ix and Iy must have the same dimensions"):
+        io.steepest_descent_images(np.zeros((4, 4, 3)), np.zeros((4, 5, 3)), np.zeros((4, 4, 4)), 2)
+    with pytest.raises(ValueError, match="Unknown type for robust error function"):
+        io.rhop(np.ones(3), 1.0, 7)
+    with pytest.raises(ValueError, match="Unknown type for robust error function"):
+        io.robust_error_function(np.ones((2, 2, 3)), 1.0, "lorentz")
