@@ -78,6 +78,11 @@ int main() {
   CHECK(ica_op_pyramid_down_dev(nullptr, 1, 1, 8, 8, 0.5, &img, &img) == ICA_EINVAL_ARG);
   CHECK(ica_op_zoom_in_parameters_dev(nullptr, 1, 1, 4, 4, 8, 8, p8) == ICA_EINVAL_ARG);
   CHECK(ica_op_transform_image_dev(nullptr, 1, 1, 8, 8, &img, p8, &img) == ICA_EINVAL_ARG);
+  CHECK(ica_op_ref_jacobian_dev(nullptr, 1, 2, 2, p8) == ICA_EINVAL_ARG);
+  CHECK(ica_op_ref_steepest_descent_dev(nullptr, 2, 2, 1, 2, p8, p8, p8, p8) == ICA_EINVAL_ARG);
+  CHECK(ica_op_ref_normal_dev(nullptr, 2, 2, 1, 2, p8, p8, nullptr, p8, p8) == ICA_EINVAL_ARG);
+  CHECK(ica_op_ref_rhop_dev(nullptr, 4, p8, 1.0, 3, p8) == ICA_EINVAL_ARG);
+  CHECK(ica_op_ref_robust_error_dev(nullptr, 2, 2, 1, p8, 1.0, 3, p8) == ICA_EINVAL_ARG);
   if (ctx) {
     // with a device: the validation order of the problem descriptor (ref :48-60) -- still no kernel launch
     pr.batch = 1; pr.height = 32; pr.width = 32; pr.channels = 7; pr.tol = 1e-3; pr.transform_type = 4; pr.nscales = 1;
