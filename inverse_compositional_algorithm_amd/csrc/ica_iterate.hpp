@@ -52,13 +52,36 @@
 #ifndef ICA_CH     // image rows per chunk, one channel
 #define ICA_CH 32
 #endif
+#ifndef ICA_TAP_BATCH   // interior band: all LDS reads of a pixel in one block, one wait (0: reads left to the compiler)
+#define ICA_TAP_BATCH 0
+#endif
+#ifndef ICA_POS_LINEAR   // interior band, homography: displacement from per-column polynomials in y (fewer instructions)
+#define ICA_POS_LINEAR 0
+#endif
 #ifndef ICA_CH3    // image rows per chunk, three channels (a 32-row tile of three channels does not fit the LDS)
 #define ICA_CH3 16
 #endif
 
 #include "ica_common.hpp"
 
+#ifndef ICA_WG_WAVES   // waves per workgroup of the iteration kernel (each walks ch / waves rows of a chunk)
+#define ICA_WG_WAVES 4
+#endif
+
 namespace ica {
+
+constexpr int kIterWaves = ICA_WG_WAVES;
+constexpr int kIterBlock = 64 * kIterWaves;
+
+#ifdef ICA_STAMP
+// Diagnostic build (tools/mkvariant.sh stamp -DICA_STAMP): shader cycles a wave spends in each phase of a chunk, summed
+// over all waves of all launches since the last read (ica_debug_stamps_tt<N> in ica_iterate_inst.hip):
+// [0] waiting at the barrier that ends the previous chunk  [1] issuing the LDS-DMA copies  [2] waiting for them to land
+// [3] the band (arithmetic + LDS reads)  [4] prologue (plan)  [5] fold  [6] whole kernel  [7] whole kernel in ticks of the constant 100 MHz clock
+constexpr int kStampWaves = 1 << 18;   // one record of 8 counters per wave of the LAST launch (no atomics: 65536 waves
+// adding to one line congest the L2 and the copies queue behind them)
+static __device__ unsigned long long ica_stamp_acc[kStampWaves * 16];
+#endif
 
 struct Mono { signed char c, a, b; };  // c * x^a * y^b; c == 0: structurally zero
 
@@ -112,7 +135,7 @@ template <int C> struct TileCfg {
   // 28.6 KB, 5 workgroups per CU, and is still 4 % faster than with 16-row chunks.
   // Three channels: 16 rows, one 39.5 KB tile, 4 workgroups per CU.
   static constexpr int ch = (C == 1) ? ICA_CH : ICA_CH3;
-  static constexpr int rw = ch / kWaves;
+  static constexpr int rw = ch / kIterWaves;
   static constexpr int p2 = 80, r2 = ch + 9;           // I2 footprint buffer: pitch (floats) x rows
   static constexpr int p1 = 72, r1 = ch + 2;           // I1 buffer: columns x_t0-4 .. x_t0+67, rows yc0-1 .. yc0+ch
   static constexpr int nbuf = (C == 1) ? ICA_NBUF : 1;
@@ -159,6 +182,59 @@ __device__ __forceinline__ int floor_to_int(float x) {
   return r;
 }
 
+
+// ---- batched LDS reads of the interior band ------------------------------------------------------------------------
+// Left to the compiler, every pair of taps is read and waited for on its own (ds_read2_b32, s_waitcnt lgkmcnt(0), two
+// multiply-adds: ten exposed LDS round trips per pixel row, the registers being short), and a wave spends most of its
+// band waiting for the LDS: measured 1260 cycles per row and wave where its ~105 vector instructions need ~600 at the
+// rate one wave can issue them (profiles/r03_stamps_*.txt).  Here all 16 taps of a pixel and the three I1 values of
+// its row are requested in ONE block of reads, the Keys weights are computed while they are in flight (the weights are
+// passed through the block so that the compiler cannot move them in front of it, and through the wait so that it cannot
+// move them behind it), and one wait follows.
+typedef float ica_f2 __attribute__((ext_vector_type(2)));
+struct Taps16 { ica_f2 p[8]; };   // p[2r] = taps 0,1 of footprint row r, p[2r+1] = taps 2,3
+
+template <int P2>
+__device__ __forceinline__ void lds_read_taps(unsigned addr, Taps16& t, float& fx, float& fy) {
+  static_assert(P2 == 80, "ds_read2_b32 offsets are written out for a pitch of 80 floats");
+  asm volatile(
+      "ds_read2_b32 %0, %10 offset1:1\n"
+      "ds_read2_b32 %1, %10 offset0:2 offset1:3\n"
+      "ds_read2_b32 %2, %10 offset0:80 offset1:81\n"
+      "ds_read2_b32 %3, %10 offset0:82 offset1:83\n"
+      "ds_read2_b32 %4, %10 offset0:160 offset1:161\n"
+      "ds_read2_b32 %5, %10 offset0:162 offset1:163\n"
+      "ds_read2_b32 %6, %10 offset0:240 offset1:241\n"
+      "ds_read2_b32 %7, %10 offset0:242 offset1:243"
+      : "=&v"(t.p[0]), "=&v"(t.p[1]), "=&v"(t.p[2]), "=&v"(t.p[3]), "=&v"(t.p[4]), "=&v"(t.p[5]), "=&v"(t.p[6]),
+        "=&v"(t.p[7]), "+v"(fx), "+v"(fy)
+      : "v"(addr)
+      : "memory");
+}
+// the centre value of the row below (`dn`) and the left / right neighbours of this row's centre, from the I1 tile;
+// `off` = byte offset of this row's centre from `addr` (a compile-time constant in the unrolled band)
+template <int OFF, int P1>
+__device__ __forceinline__ void lds_read_i1(unsigned addr, float& dn, float& lf, float& rt) {
+  asm volatile(
+      "ds_read_b32 %0, %3 offset:%4\n"
+      "ds_read_b32 %1, %3 offset:%5\n"
+      "ds_read_b32 %2, %3 offset:%6"
+      : "=&v"(dn), "=&v"(lf), "=&v"(rt)
+      : "v"(addr), "n"(OFF + P1 * 4), "n"(OFF - 4), "n"(OFF + 4)
+      : "memory");
+}
+__device__ __forceinline__ void lds_wait_taps(Taps16& t, float (&wx)[4], float (&wy)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(t.p[0]), "+v"(t.p[1]), "+v"(t.p[2]), "+v"(t.p[3]), "+v"(t.p[4]), "+v"(t.p[5]), "+v"(t.p[6]),
+                 "+v"(t.p[7]), "+v"(wx[0]), "+v"(wx[1]), "+v"(wx[2]), "+v"(wx[3]), "+v"(wy[0]), "+v"(wy[1]), "+v"(wy[2]),
+                 "+v"(wy[3])
+               :
+               : "memory");
+}
+__device__ __forceinline__ void lds_wait_i1(float& dn, float& lf, float& rt) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dn), "+v"(lf), "+v"(rt) : : "memory");
+}
+
 template <bool PROJ>
 __device__ __forceinline__ void displacement_col(const float* A, float cx, float cy, float gx, float xf, float yf,
                                                  float& dx, float& dy) {
@@ -199,7 +275,7 @@ __device__ __forceinline__ float rho_prime_t(float t2, float lam2) {
 // workgroup: barrier, expand chunk k, barrier, start the copy of chunk k+1, compute chunk k.
 template <int TT, int MODE, int C, int RT, bool U8>
 // (second launch bound = waves per SIMD the register allocator must leave room for: what the LDS footprint allows)
-__global__ __launch_bounds__(kBlock, (C == 1 ? (U8 ? ICA_ITER_WAVES_U8 : ICA_ITER_WAVES) : U8 ? 3 : 4)) void ica_iterate_kernel(LevelArgs a) {
+__global__ __launch_bounds__(kIterBlock, (C == 1 ? (U8 ? ICA_ITER_WAVES_U8 : ICA_ITER_WAVES) : U8 ? 3 : 4)) void ica_iterate_kernel(LevelArgs a) {
   using TIn = std::conditional_t<U8, unsigned char, float>;
   constexpr int ES = (int)sizeof(TIn);    // bytes per image element in HBM
   constexpr int N = NP<TT>::n;
@@ -248,6 +324,10 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? (U8 ? ICA_ITER_WAVES_U8 : ICA_ITE
   } else if (pair_slot >= a.n_pairs) {
     return;
   }
+#ifdef ICA_STAMP
+  long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const long long stamp_begin = clock64(), stamp_rt_begin = wall_clock64();
+#endif
   const int tx = tile_id % a.tiles_x, ty = tile_id / a.tiles_x;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -424,7 +504,7 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? (U8 ? ICA_ITER_WAVES_U8 : ICA_ITE
   //  the 25 I2 rows, 2 of the 18 I1 rows -- was built and measured: a quarter fewer L1 requests, but 9 % MORE time;
   //  the move and its dependency sit in front of the copies.  profiles/r02_ablation.txt)
   auto issue = [&](int k, int buf) {
-#if defined(ICA_ABLATE) && ICA_ABLATE == 2
+#if defined(ICA_ABLATE) && (ICA_ABLATE & 2)   // (ICA_ABLATE is a set of bits: 1 copies only, 2 no copies, 4 lane-linear taps, 8 no barriers)
     return;  // timing-only build: no LDS-DMA
 #endif
     const int px = plan_px(k), y_lo = plan_ylo(k);
@@ -438,8 +518,8 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? (U8 ? ICA_ITER_WAVES_U8 : ICA_ITE
       // may wrap below 0 (row -1): then out of range.  A skipped chunk gets an out-of-range base.
       const unsigned base1 = skip ? 0x40000000u : (unsigned)(((yc0 - 1) * W + x_t0) * ES);
 #pragma unroll
-      for (int qq = 0; qq < (NQ1 + kWaves - 1) / kWaves; ++qq) {
-        const int q = wave + qq * kWaves;      // this wave's row group (wave-uniform)
+      for (int qq = 0; qq < (NQ1 + kIterWaves - 1) / kIterWaves; ++qq) {
+        const int q = wave + qq * kIterWaves;      // this wave's row group (wave-uniform)
         // Lanes past the tile's last row must not take part at all: an out-of-range lane still writes its (zero) result
         // to LDS, which would land in the neighbouring tile.
         const int rows = min(RP1, R1 - RP1 * q);
@@ -463,8 +543,8 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? (U8 ? ICA_ITER_WAVES_U8 : ICA_ITE
             (void*)I2, 0, bh ? (int)(((size_t)(C - 1) * plane + (size_t)(y_lo + bh) * W) * ES) : 0, 0x00020000);
         const unsigned base2 = (unsigned)((y_lo * W + x_lo) * ES);
 #pragma unroll
-        for (int qq = 0; qq < (NQ2 + kWaves - 1) / kWaves; ++qq) {
-          const int q = wave + qq * kWaves;
+        for (int qq = 0; qq < (NQ2 + kIterWaves - 1) / kIterWaves; ++qq) {
+          const int q = wave + qq * kIterWaves;
           const int rows = min(RP2, R2 - RP2 * q);
           if (q < NQ2 && lane < V2 * rows) {
             TIn* dst = b2 + RP2 * q * P2;
@@ -479,7 +559,7 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? (U8 ? ICA_ITER_WAVES_U8 : ICA_ITE
       }
     } else if constexpr (!U8) {
       if (px & (1 << 29)) return;
-      for (int r = wave; r < R1; r += kWaves) {
+      for (int r = wave; r < R1; r += kIterWaves) {
         const int yy = yc0 - 1 + r;
         if (yy < 0 || yy >= H) continue;
 #pragma unroll
@@ -492,7 +572,7 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? (U8 ? ICA_ITER_WAVES_U8 : ICA_ITE
       }
       if (kB && (px & (1 << 30))) {
         const int x_lo = px & 0xFFFFF;
-        for (int r = wave; r < R2; r += kWaves) {
+        for (int r = wave; r < R2; r += kIterWaves) {
           const int yy = y_lo + r;
           if (yy >= H) break;
 #pragma unroll
@@ -508,7 +588,7 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? (U8 ? ICA_ITER_WAVES_U8 : ICA_ITE
   };
 
   if (!w4) {  // the dword copy path skips out-of-image lanes instead of zero-filling them: start from finite LDS
-    for (int i = threadIdx.x; i < kLdsFloats; i += kBlock) lds[i] = 0.f;
+    for (int i = threadIdx.x; i < kLdsFloats; i += kIterBlock) lds[i] = 0.f;
     __syncthreads();
   }
 
@@ -529,7 +609,7 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? (U8 ? ICA_ITER_WAVES_U8 : ICA_ITE
   [[maybe_unused]] auto expand = [&](int k) {
     if (w4) {
       const unsigned* s32 = reinterpret_cast<const unsigned*>(lds + TC::buf_floats);
-      for (int e = threadIdx.x; e < TC::buf_floats / 4; e += kBlock) {
+      for (int e = threadIdx.x; e < TC::buf_floats / 4; e += kIterBlock) {
         const unsigned u = s32[e];
         float4 v;
         v.x = (float)(u & 0xffu); v.y = (float)((u >> 8) & 0xffu); v.z = (float)((u >> 16) & 0xffu); v.w = (float)(u >> 24);
@@ -537,7 +617,7 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? (U8 ? ICA_ITER_WAVES_U8 : ICA_ITE
       }
     } else {
       const int px = plan_px(k), y_lo = plan_ylo(k), x_lo = px & 0xFFFFF, yc0 = y_begin + k * CH;
-      for (int e = threadIdx.x; e < TC::buf_floats; e += kBlock) {
+      for (int e = threadIdx.x; e < TC::buf_floats; e += kIterBlock) {
         const bool two = e < C * P2 * R2;                  // I2 footprint region, else I1 tile region
         const int f = two ? e : e - C * P2 * R2, pitch = two ? P2 : P1, rows = two ? R2 : R1;
         const int c = f / (pitch * rows), g = f - c * pitch * rows, r = g / pitch, col = g - r * pitch;
@@ -564,6 +644,9 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? (U8 ? ICA_ITER_WAVES_U8 : ICA_ITE
       if (cls_mask[c]) return __builtin_ctz(cls_mask[c]);
     return -1;
   };
+#ifdef ICA_STAMP
+  stamp[4] = clock64() - stamp_begin;
+#endif
   int ring = 0;  // the float tile the next computed chunk sits in (two tiles: they alternate)
   {
     const unsigned all = cls_mask[0] | cls_mask[1] | cls_mask[2];
@@ -581,9 +664,26 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? (U8 ? ICA_ITER_WAVES_U8 : ICA_ITE
       __syncthreads();                // the float tile holds chunk k; the staging area is free
       if (w4 && next >= 0) issue(next, 0);
     } else if (NBUF == 1) {
+#ifdef ICA_STAMP
+      const long long s0 = clock64();
+#endif
+#if !(defined(ICA_ABLATE) && (ICA_ABLATE & 8))
       __syncthreads();  // everyone is done reading the single buffer
+#endif
+#ifdef ICA_STAMP
+      const long long s1 = clock64();
+#endif
       issue(k, 0);
+#ifdef ICA_STAMP
+      const long long s2 = clock64();
+#endif
+#if !(defined(ICA_ABLATE) && (ICA_ABLATE & 8))
       __syncthreads();  // drains this wave's LDS-DMA (vmcnt(0)) and publishes chunk k
+#endif
+#ifdef ICA_STAMP
+      const long long s3 = clock64();
+      stamp[0] += s1 - s0; stamp[1] += s2 - s1; stamp[2] += s3 - s2; stamp[3] -= s3;
+#endif
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -674,12 +774,17 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? (U8 ? ICA_ITER_WAVES_U8 : ICA_ITE
       [[maybe_unused]] const float cx = fmaf(A[0], xf, A[2]), cy = fmaf(A[3], xf, A[5]), gxc = A[6] * xf, nxf = -xf;
       // wave-uniform operands, copied into VGPRs here (not kept in VGPRs across the chunk loop: registers are short)
       [[maybe_unused]] const float a1v = pin_vgpr(A[1]), a4v = pin_vgpr(A[4]), a7v = pin_vgpr(A[7]);
+#if ICA_POS_LINEAR
+      [[maybe_unused]] const float pd0 = 1.0f + gxc, psx = fmaf(-xf, a7v, a1v), pix = fmaf(nxf, gxc, cx), psy = a4v - gxc,
+                                   na7v = -a7v;
+#endif
       [[maybe_unused]] const float hi_v = pin_vgpr(hi), lam2_v = pin_vgpr(lam2);
       // I1: a row's up / down neighbours are the centre values of the rows before / after it, so the column is read
       // once per row (rolling window of three values per channel)
       float cu[C], cm[C], cd[C];
 #pragma unroll
       for (int c = 0; c < C; ++c) { cm[c] = i1p[c * P1 * R1]; cd[c] = i1p[c * P1 * R1 + P1]; }
+      [[maybe_unused]] const unsigned i1a = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)i1p;
 #pragma unroll
       for (int i = 0; i < RW; ++i) {
         const float yf = i == 0 ? yf0 : yf0 + (float)i;  // exact (small integers); a VGPR because yf0 is one
@@ -689,32 +794,61 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? (U8 ? ICA_ITER_WAVES_U8 : ICA_ITE
           live = col_ok & (y < y_end) & !((y < a.delta) | (y >= H - a.delta));
         }
         float ix2[C], iy2[C];
+        constexpr bool kBatch = (ICA_TAP_BATCH != 0) && kB && (C == 1);
+        [[maybe_unused]] float i1dn = 0.f, i1lf = 0.f, i1rt = 0.f;
+        if constexpr (kBatch) {
+          // (the I1 reads are requested first: they do not depend on the sampling position)
+          switch (i) {   // the row offset must be an immediate
+            case 0: lds_read_i1<1 * P1 * 4, P1>(i1a, i1dn, i1lf, i1rt); break;
+            case 1: lds_read_i1<2 * P1 * 4, P1>(i1a, i1dn, i1lf, i1rt); break;
+            case 2: lds_read_i1<3 * P1 * 4, P1>(i1a, i1dn, i1lf, i1rt); break;
+            case 3: lds_read_i1<4 * P1 * 4, P1>(i1a, i1dn, i1lf, i1rt); break;
+            case 4: lds_read_i1<5 * P1 * 4, P1>(i1a, i1dn, i1lf, i1rt); break;
+            case 5: lds_read_i1<6 * P1 * 4, P1>(i1a, i1dn, i1lf, i1rt); break;
+            case 6: lds_read_i1<7 * P1 * 4, P1>(i1a, i1dn, i1lf, i1rt); break;
+            default: lds_read_i1<8 * P1 * 4, P1>(i1a, i1dn, i1lf, i1rt); break;
+          }
+        } else {
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-          const float* q = i1p + c * P1 * R1 + (i + 1) * P1;
-          cu[c] = cm[c]; cm[c] = cd[c]; cd[c] = q[P1];
-          ix2[c] = q[1] - q[-1];
-          iy2[c] = cd[c] - cu[c];
+          for (int c = 0; c < C; ++c) {
+            const float* q = i1p + c * P1 * R1 + (i + 1) * P1;
+            cu[c] = cm[c]; cm[c] = cd[c]; cd[c] = q[P1];
+            ix2[c] = q[1] - q[-1];
+            iy2[c] = cd[c] - cu[c];
+          }
         }
         float di[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) di[c] = 0.f;
         if constexpr (kB) {
-          float dxw = fmaf(a1v, yf, cx), dyw = fmaf(a4v, yf, cy);
+          float dxw, dyw;
           if constexpr (kProj) {
+#if ICA_POS_LINEAR
+            // numerators and denominator of the displacement as polynomials in y with per-column coefficients (formed
+            // once per band): x' - x = ((a1 - a7 x) y + (cx - x gxc)) / d,  y' - y = (-a7 y^2 + (a4 - gxc) y + cy) / d,
+            // d = a7 y + (1 + gxc): 5 multiply-adds and a reciprocal per pixel instead of 7 and an addition
+            const float d = fmaf(a7v, yf, pd0);
+            const float r = rcp_nr(d);
+            dxw = fmaf(psx, yf, pix) * r;
+            dyw = fmaf(na7v, yf * yf, fmaf(psy, yf, cy)) * r;
+#else
+            dxw = fmaf(a1v, yf, cx); dyw = fmaf(a4v, yf, cy);
             const float g = fmaf(a7v, yf, gxc);
             const float r = rcp_nr(1.0f + g);
             dxw = fmaf(nxf, g, dxw) * r;
             dyw = fmaf(-yf, g, dyw) * r;
+#endif
+          } else {
+            dxw = fmaf(a1v, yf, cx); dyw = fmaf(a4v, yf, cy);
           }
           const float flx = floorf(dxw), fly = floorf(dyw);
-          const float fx = dxw - flx, fy = dyw - fly;
+          float fx = dxw - flx, fy = dyw - fly;
           float af;  // fly * (P2 * 4) + tap0f with the pitch as a literal (no register for it)
           asm("v_fmamk_f32 %0, %1, %3, %2" : "=v"(af) : "v"(fly), "v"(tap0f), "n"(kPitchBits));
           af = fmaf(flx, 4.0f, af);
           // (signed conversion: in a border chunk the address of row 0 of the band may lie below the tile -- a frame
           //  row above the image -- while a later, live row of the same band is inside)
-#if defined(ICA_ABLATE) && ICA_ABLATE == 3  // timing-only build: every tap read is lane-linear (no LDS bank conflicts)
+#if defined(ICA_ABLATE) && (ICA_ABLATE & 4)  // timing-only build: every tap read is lane-linear (no LDS bank conflicts)
           int zero_s;
           asm volatile("s_mov_b32 %0, 0" : "=s"(zero_s));
           const int lane_b = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) * 4;
@@ -726,6 +860,28 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? (U8 ? ICA_ITER_WAVES_U8 : ICA_ITE
           if (i > 0) asm("" : "+v"(addr));
 #endif
           float wx[4], wy[4];
+          if constexpr (kBatch) {
+            Taps16 t;
+            lds_read_taps<P2>(addr, t, fx, fy);
+            keys_weights(fx, wx);     // while the reads are in flight
+            keys_weights(fy, wy);
+            lds_wait_taps(t, wx, wy);
+            lds_wait_i1(i1dn, i1lf, i1rt);
+            cu[0] = cm[0]; cm[0] = cd[0]; cd[0] = i1dn;
+            ix2[0] = i1rt - i1lf;
+            iy2[0] = cd[0] - cu[0];
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float sr = wx[0] * t.p[2 * r].x;
+              sr = __builtin_fmaf(wx[1], t.p[2 * r].y, sr);
+              sr = __builtin_fmaf(wx[2], t.p[2 * r + 1].x, sr);
+              sr = __builtin_fmaf(wx[3], t.p[2 * r + 1].y, sr);
+              v = (r == 0) ? wy[0] * sr : __builtin_fmaf(wy[r], sr, v);
+            }
+            di[0] = __builtin_amdgcn_fmed3f(v, lo, hi_v) - cm[0];  // clip (skimage warp), ref :114
+            if constexpr (MASKED) di[0] = live ? di[0] : 0.0f;
+          } else {
           keys_weights(fx, wx);
           keys_weights(fy, wy);
 #pragma unroll
@@ -743,6 +899,7 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? (U8 ? ICA_ITER_WAVES_U8 : ICA_ITE
             }
             di[c] = __builtin_amdgcn_fmed3f(v, lo, hi_v) - cm[c];  // clip (skimage warp), ref :114
             if constexpr (MASKED) di[c] = live ? di[c] : 0.0f;
+          }
           }
         }
         float w = 1.0f;
@@ -871,7 +1028,7 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? (U8 ? ICA_ITER_WAVES_U8 : ICA_ITE
         accumulate(w, ix2, iy2, di, yf);
       }
     };
-#if defined(ICA_ABLATE) && ICA_ABLATE == 1
+#if defined(ICA_ABLATE) && (ICA_ABLATE & 1)
     if (a.delta < 0)  // timing-only build: staging and barriers only
 #endif
     {
@@ -886,6 +1043,9 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? (U8 ? ICA_ITER_WAVES_U8 : ICA_ITE
       else if (staged) band_careful(std::true_type{});
       else band_careful(std::false_type{});
     }
+#ifdef ICA_STAMP
+    if constexpr (!U8 && NBUF == 1) stamp[3] += clock64();
+#endif
   };
   // Ring protocol (two tiles): chunk `next` is in flight while chunk k is computed.  A wave's copies retire in order;
   // the barrier makes every wave's part visible, and also means everyone has finished reading the chunk before k,
@@ -916,6 +1076,9 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? (U8 ? ICA_ITER_WAVES_U8 : ICA_ITE
   }
   // The y-moments of one lane's column over the whole tile (<= 64 rows per lane) stay in fp32 registers; they are
   // promoted to fp64 here, before x powers up to x^4 are applied and 64 lanes x 4 waves x tiles are summed.
+#ifdef ICA_STAMP
+  const long long stamp_fold = clock64();
+#endif
   double m64[NMOM];
 #pragma unroll
   for (int i = 0; i < NMOM; ++i) m64[i] = (double)m32[i];
@@ -924,7 +1087,7 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? (U8 ? ICA_ITER_WAVES_U8 : ICA_ITE
   __syncthreads();
   double* mom = reinterpret_cast<double*>(lds);   // [NMOM][64] moments of the whole tile, per column
   double* con = mom + NMOM * 64;                  // [N + NT][64] per-column contribution to each output sum
-  for (int wv = 0; wv < kWaves; ++wv) {           // waves take turns: deterministic wave order
+  for (int wv = 0; wv < kIterWaves; ++wv) {           // waves take turns: deterministic wave order
     if (wave == wv) {
 #pragma unroll
       for (int i = 0; i < NMOM; ++i) {
@@ -953,7 +1116,7 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? (U8 ? ICA_ITER_WAVES_U8 : ICA_ITE
       int e = 0;
 #pragma unroll
       for (int k = 0; k < N; ++k) {   // b_k (halved: the gradients were accumulated as 2*Ix, 2*Iy)
-        if (kB && (e & 3) == wave && e >= e_lo && e < e_hi) {
+        if (kB && ((e & 3) == wave) && e >= e_lo && e < e_hi) {
           constexpr Mono one{1, 0, 0};
           const Mono jx = jac_x(TT, k), jy = jac_y(TT, k);
           double v = 0.0;
@@ -967,7 +1130,7 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? (U8 ? ICA_ITER_WAVES_U8 : ICA_ITE
       for (int k = 0; k < N; ++k) {
 #pragma unroll
         for (int m = k; m < N; ++m) {  // H_km (quartered)
-          if (kH && (e & 3) == wave && e >= e_lo && e < e_hi) {
+          if (kH && ((e & 3) == wave) && e >= e_lo && e < e_hi) {
             const Mono jxk = jac_x(TT, k), jyk = jac_y(TT, k), jxm = jac_x(TT, m), jym = jac_y(TT, m);
             double v = 0.0;
             if (jxk.c && jxm.c) v += term(jxk, jxm, ML::oxx);
@@ -1000,6 +1163,25 @@ __global__ __launch_bounds__(kBlock, (C == 1 ? (U8 ? ICA_ITER_WAVES_U8 : ICA_ITE
     }
     if (kFoldSplit && part == 0) __syncthreads();
   }
+#ifdef ICA_STAMP
+  {
+    const long long e = clock64();
+    stamp[5] = e - stamp_fold;
+    stamp[6] = e - stamp_begin;
+    stamp[7] = wall_clock64() - stamp_rt_begin;  // 100 MHz ticks
+    if (lane == 0) {
+      unsigned long long* rec = ica_stamp_acc + (size_t)((blockIdx.x * kIterWaves + wave) & (kStampWaves - 1)) * 16;
+      for (int i = 0; i < 8; ++i) rec[i] = (unsigned long long)stamp[i];
+      rec[8] = (unsigned long long)stamp_rt_begin;                       // absolute, 100 MHz
+      rec[9] = (unsigned long long)(stamp_rt_begin + stamp[7]);
+      unsigned hw_id, xcc_id;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+      rec[10] = hw_id;
+      rec[11] = xcc_id;
+    }
+  }
+#endif
 }
 
 }  // namespace ica

@@ -13,11 +13,11 @@ namespace {
 template <int TT, int MODE, int RT>
 void launch_c(int channels, unsigned blocks, hipStream_t st, const LevelArgs& a) {
   if (a.u8) {  // this level's images are uint8 in HBM (level 0 of an ICA_STORAGE_U8 problem)
-    if (channels == 1) hipLaunchKernelGGL((ica_iterate_kernel<TT, MODE, 1, RT, true>), dim3(blocks), dim3(kBlock), 0, st, a);
-    else hipLaunchKernelGGL((ica_iterate_kernel<TT, MODE, 3, RT, true>), dim3(blocks), dim3(kBlock), 0, st, a);
+    if (channels == 1) hipLaunchKernelGGL((ica_iterate_kernel<TT, MODE, 1, RT, true>), dim3(blocks), dim3(kIterBlock), 0, st, a);
+    else hipLaunchKernelGGL((ica_iterate_kernel<TT, MODE, 3, RT, true>), dim3(blocks), dim3(kIterBlock), 0, st, a);
   } else {
-    if (channels == 1) hipLaunchKernelGGL((ica_iterate_kernel<TT, MODE, 1, RT, false>), dim3(blocks), dim3(kBlock), 0, st, a);
-    else hipLaunchKernelGGL((ica_iterate_kernel<TT, MODE, 3, RT, false>), dim3(blocks), dim3(kBlock), 0, st, a);
+    if (channels == 1) hipLaunchKernelGGL((ica_iterate_kernel<TT, MODE, 1, RT, false>), dim3(blocks), dim3(kIterBlock), 0, st, a);
+    else hipLaunchKernelGGL((ica_iterate_kernel<TT, MODE, 3, RT, false>), dim3(blocks), dim3(kIterBlock), 0, st, a);
   }
 }
 
@@ -49,3 +49,20 @@ void ICA_CAT(launch_iterate_tt, ICA_INST_TT)(int mode, int channels, int robust_
 }
 
 }  // namespace ica
+
+#ifdef ICA_STAMP
+// diagnostic builds: copy out and reset the per-wave records of this unit's kernels (see ica_iterate.hpp):
+// out = [kStampWaves][16] unsigned long long (the waves of the last launch; a record with [6] == 0 is unused)
+#define ICA_STAMP_FN2(n) ica_debug_stamps_tt##n
+#define ICA_STAMP_FN(n) ICA_STAMP_FN2(n)
+extern "C" __attribute__((visibility("default"))) int ICA_STAMP_FN(ICA_INST_TT)(unsigned long long* out, int max_records) {
+  if (max_records < ica::kStampWaves) return ica::kStampWaves;
+  const size_t bytes = (size_t)ica::kStampWaves * 16 * sizeof(unsigned long long);
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ica::ica_stamp_acc), bytes) != hipSuccess) return -2;
+  void* dev = nullptr;
+  if (hipGetSymbolAddress(&dev, HIP_SYMBOL(ica::ica_stamp_acc)) != hipSuccess) return -3;
+  if (hipMemset(dev, 0, bytes) != hipSuccess) return -4;
+  return 0;
+}
+#endif
