@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ICA_ABI_VERSION 1
+#define ICA_ABI_VERSION 3   /* 3: ica_problem.storage, void* image pointers, ica_op_ref_* (rounds 2-3) */
 #define ICA_MAX_PARAMS 8
 #define ICA_MAX_SCALES 16
 #define ICA_MAX_CHANNELS 4

@@ -5,6 +5,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+ICA_ABI_VERSION = 3   # include/ica_hip.h
 ICA_MAX_SCALES = 16
 ICA_TRACE_STRIDE = 10
 ICA_FLAG_EXACT_UPDATE = 1
@@ -84,13 +85,20 @@ def load() -> C.CDLL:
         raise RuntimeError(
             f"{LIB_PATH} is missing: the HIP extension has not been built (python -m "
             "inverse_compositional_algorithm_amd.build, or __graft_entry__.build()). There is no CPU fallback.")
+    if "ICA_LIB" not in os.environ:
+        # the in-tree library must be the one build() wrote from the present sources (experiment builds carry no stamp)
+        from . import build
+        if os.path.isdir(build.CSRC) and build.is_stale():
+            raise RuntimeError(f"{LIB_PATH} does not match its sources or its build stamp: rebuild it "
+                               "(python -m inverse_compositional_algorithm_amd.build)")
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.ica_version() != 1:
-        raise RuntimeError("libica_hip.so ABI version mismatch")
+    if lib.ica_version() != ICA_ABI_VERSION:
+        raise RuntimeError(f"libica_hip.so has ABI version {lib.ica_version()}, this package binds version "
+                           f"{ICA_ABI_VERSION}: rebuild it (python -m inverse_compositional_algorithm_amd.build)")
     _lib = lib
     return lib
 

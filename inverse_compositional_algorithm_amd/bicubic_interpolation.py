@@ -8,7 +8,7 @@ weights, NaN wherever any of the 16 taps falls outside the image, result clipped
 The reference's unused pure-Python / Numba interpolators (`:8-152`) are out of scope."""
 import numpy as np
 
-from .inverse_compositional_algorithm import _engine, _to_device, _to_host
+from .inverse_compositional_algorithm import _to_device, _to_host, _use_engine
 from .transformation import _tt
 
 
@@ -17,8 +17,7 @@ def bicubic_interpolation_skimage(image: np.ndarray, params: np.ndarray, transfo
     image = np.asarray(image)
     if image.ndim != 3:
         raise ValueError("image must have its channels in the last dimension")
-    eng = _engine()
-    img = _to_device(image, eng)
     p = np.zeros((1, 8))
     p[0, :len(params)] = np.asarray(params, dtype=np.float64)
-    return _to_host(eng.warp(img, p, _tt(transformation_type)))
+    with _use_engine() as eng:
+        return _to_host(eng.warp(_to_device(image, eng), p, _tt(transformation_type)))

@@ -79,11 +79,32 @@ def lib_path() -> str:
     return LIB
 
 
+def lib_digest(path: str = None) -> str:
+    """sha256 of the shared library's bytes."""
+    h = hashlib.sha256()
+    with open(path or LIB, "rb") as fh:
+        for block in iter(lambda: fh.read(1 << 20), b""):
+            h.update(block)
+    return h.hexdigest()
+
+
+def read_stamp() -> tuple:
+    """(source fingerprint, library digest) recorded by the last build, ('', '') without a stamp."""
+    if not os.path.isfile(STAMP):
+        return "", ""
+    with open(STAMP) as fh:
+        lines = fh.read().split()
+    return (lines + ["", ""])[0], (lines + ["", ""])[1]
+
+
 def is_stale() -> bool:
+    """True unless the library on disk is the one the last build() wrote from the present sources and flags: the stamp
+    holds the fingerprint of the sources AND the digest of the .so, so a library overwritten by some other tool (a
+    partial link, a truncated copy, a foreign file) is stale even though the sources did not change."""
     if not os.path.isfile(LIB) or not os.path.isfile(STAMP):
         return True
-    with open(STAMP) as fh:
-        return fh.read().strip() != fingerprint()
+    fp, digest = read_stamp()
+    return fp != fingerprint() or digest != lib_digest()
 
 
 def build_variant(out: str, extra: list, verbose: bool = False) -> str:
@@ -112,7 +133,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             list(pool.map(run, cmds[:-1]))
         run(cmds[-1])
     with open(STAMP, "w") as fh:
-        fh.write(fp + "\n")
+        fh.write(fp + "\n" + lib_digest() + "\n")
     return LIB
 
 

@@ -129,6 +129,8 @@ int validate(const ica_problem* pr) {
   if (pr->channels < 1 || pr->channels > ICA_MAX_CHANNELS) return ICA_EINVAL_SHAPE;
   if (pr->batch <= 0 || pr->height <= 0 || pr->width <= 0) return ICA_EINVAL_ARG;
   if (pr->height >= (1 << 20) || pr->width >= (1 << 20)) return ICA_EINVAL_ARG;  // 20-bit fields in the chunk plan
+  // the iteration kernel addresses one pair's planes through 32-bit buffer offsets (num_records and byte offsets are int)
+  if ((size_t)pr->channels * (size_t)pr->height * (size_t)pr->width * 4 >= ((size_t)1 << 31)) return ICA_EINVAL_ARG;
   if (!(pr->tol < 0.01)) return ICA_EINVAL_TOL;  // ref :59-60
   if (nparams_of(pr->transform_type) < 0) return ICA_EINVAL_TRANSFORM;
   if (pr->robust_type < ICA_QUADRATIC || pr->robust_type > ICA_CHARBONNIER) return ICA_EINVAL_ROBUST;
@@ -369,12 +371,9 @@ int launch_pyramid_down(ica_ctx* ctx, int batch, int C, int H, int W, int h, int
     const dim3 gv(xblocks, (vgroups + kWaves - 1) / kWaves, np);
     float* pp = part ? part + (size_t)p0 * vgroups * xblocks * 2 : nullptr;
     if (generic_v) {  // very small nu: window of 16 outputs wider than the tiled pass is sized for
-      if constexpr (kF32)
-        hipLaunchKernelGGL(ica_resample_generic_kernel<true>, dim3((W + kBlock - 1) / kBlock, h, np), dim3(kBlock), 0,
-                           ctx->stream, in + (size_t)p0 * H * W, tmp + (size_t)p0 * h * W, C, W, oy->view(),
-                           (const float*)nullptr);
-      else
-        return ICA_EINVAL_ARG;  // (rejected up front by validate_storage)
+      hipLaunchKernelGGL((ica_resample_generic_kernel<true, TIn>), dim3((W + kBlock - 1) / kBlock, h, np), dim3(kBlock), 0,
+                         ctx->stream, in + (size_t)p0 * H * W, tmp + (size_t)p0 * h * W, C, W, oy->view(),
+                         (const float*)nullptr);
     } else if (vec4)
       hipLaunchKernelGGL((ica_resample_v_kernel<4, TIn>), gv, dim3(kBlock), 0, ctx->stream, in + (size_t)p0 * H * W,
                          tmp + (size_t)p0 * h * W, np, C, W, oy->view(), pp);
@@ -389,7 +388,7 @@ int launch_pyramid_down(ica_ctx* ctx, int batch, int C, int H, int W, int h, int
     const int np = std::min(step, planes - p0);
     const dim3 gh((w + 63) / 64, (h + kRowsH - 1) / kRowsH, np);
     if (generic_h)
-      hipLaunchKernelGGL(ica_resample_generic_kernel<false>, dim3((w + kBlock - 1) / kBlock, h, np), dim3(kBlock), 0,
+      hipLaunchKernelGGL((ica_resample_generic_kernel<false, float>), dim3((w + kBlock - 1) / kBlock, h, np), dim3(kBlock), 0,
                          ctx->stream, tmp + (size_t)p0 * h * W, out + (size_t)p0 * h * w, C, h, ox->view(),
                          mm_out + (size_t)(p0 / C) * 2);
     else if (W % 2 == 0)  // rows of the intermediate image are 8-byte aligned: stage with 8-byte loads
@@ -405,7 +404,7 @@ int launch_pyramid_down(ica_ctx* ctx, int batch, int C, int H, int W, int h, int
 
 // variant 1 (ICA_ACCUM=1) is the simple direct-gather kernel, kept as an in-library cross-check of the LDS-staged one
 template <int TT, int MODE>
-void launch_accumulate_c(int variant, int C, dim3 grid, hipStream_t st, const LevelArgs& a) {
+bool launch_accumulate_c(int variant, int C, dim3 grid, hipStream_t st, const LevelArgs& a) {
   // 1 and 3 channels (gray / RGB, the reference's data) run the LDS-staged kernel; 2 and 4 channels (the reference's
   // robust entry point takes any channel count, ref :168-177) run the direct-gather kernel
   if ((variant == 1 && !a.u8) || C == 2 || C == 4) {  // (the cross-check kernel reads float32 images only)
@@ -415,34 +414,44 @@ void launch_accumulate_c(int variant, int C, dim3 grid, hipStream_t st, const Le
       case 3: hipLaunchKernelGGL((ica_accumulate_kernel<TT, MODE, 3>), grid, dim3(kBlock), 0, st, a); break;
       default: hipLaunchKernelGGL((ica_accumulate_kernel<TT, MODE, 4>), grid, dim3(kBlock), 0, st, a); break;
     }
+    return true;
   } else {
     // 1-D grid: (pairs rounded up to a multiple of 8) x tiles, decoded XCD-aware inside the kernel; launches of fewer
     // than kFlatMapBelow pairs (a.n_pairs = pairs of the launch) use a flat pairs x tiles grid instead
     const unsigned blocks = (unsigned)((int)grid.y < kFlatMapBelow ? grid.y * grid.x : ((grid.y + 7) / 8) * 8 * grid.x);
     LevelArgs al = a;
     al.n_pairs = (int)grid.y;  // the kernel picks the same map from it
-    launch_iterate(TT, MODE, C, a.robust_type, blocks, st, al);
+    return launch_iterate(TT, MODE, C, a.robust_type, blocks, st, al);
   }
 }
 
 template <int MODE>
-void launch_accumulate(int variant, int tt, int C, dim3 grid, hipStream_t st, const LevelArgs& a) {
+bool launch_accumulate(int variant, int tt, int C, dim3 grid, hipStream_t st, const LevelArgs& a) {
   switch (tt) {
-    case ICA_TRANSLATION: launch_accumulate_c<ICA_TRANSLATION, MODE>(variant, C, grid, st, a); break;
-    case ICA_EUCLIDEAN: launch_accumulate_c<ICA_EUCLIDEAN, MODE>(variant, C, grid, st, a); break;
-    case ICA_SIMILARITY: launch_accumulate_c<ICA_SIMILARITY, MODE>(variant, C, grid, st, a); break;
-    case ICA_AFFINITY: launch_accumulate_c<ICA_AFFINITY, MODE>(variant, C, grid, st, a); break;
-    default: launch_accumulate_c<ICA_HOMOGRAPHY, MODE>(variant, C, grid, st, a); break;
+    case ICA_TRANSLATION: return launch_accumulate_c<ICA_TRANSLATION, MODE>(variant, C, grid, st, a);
+    case ICA_EUCLIDEAN: return launch_accumulate_c<ICA_EUCLIDEAN, MODE>(variant, C, grid, st, a);
+    case ICA_SIMILARITY: return launch_accumulate_c<ICA_SIMILARITY, MODE>(variant, C, grid, st, a);
+    case ICA_AFFINITY: return launch_accumulate_c<ICA_AFFINITY, MODE>(variant, C, grid, st, a);
+    default: return launch_accumulate_c<ICA_HOMOGRAPHY, MODE>(variant, C, grid, st, a);
   }
 }
 
-void launch_accumulate_mode(const ica_ctx* ctx, int mode, int tt, int C, dim3 grid, hipStream_t st, const LevelArgs& a) {
+int launch_accumulate_mode(ica_ctx* ctx, int mode, int tt, int C, dim3 grid, hipStream_t st, const LevelArgs& a) {
   const int v = ctx->accum_variant;
-  if (mode == kModeL2) launch_accumulate<kModeL2>(v, tt, C, grid, st, a);
-  else if (mode == kModeRobust) launch_accumulate<kModeRobust>(v, tt, C, grid, st, a);
-  else if (mode == kModeL2First && v == 2 && (C == 1 || C == 3)) launch_accumulate<kModeL2First>(v, tt, C, grid, st, a);
-  else if (mode == kModeL2First) launch_accumulate<kModeRobust>(v, tt, C, grid, st, a);  // v1: weights 1 at run time
-  else launch_accumulate<kModeHessian>(v, tt, C, grid, st, a);
+  bool ok;
+  if (mode == kModeL2) ok = launch_accumulate<kModeL2>(v, tt, C, grid, st, a);
+  else if (mode == kModeRobust) ok = launch_accumulate<kModeRobust>(v, tt, C, grid, st, a);
+  // (uint8 levels always run the LDS-staged kernel -- the direct-gather kernel reads float32 only -- so with ICA_ACCUM=1
+  //  their first L2 iteration takes the staged kernel's own first-iteration mode too)
+  else if (mode == kModeL2First && (v == 2 || a.u8) && (C == 1 || C == 3)) ok = launch_accumulate<kModeL2First>(v, tt, C, grid, st, a);
+  else if (mode == kModeL2First) ok = launch_accumulate<kModeRobust>(v, tt, C, grid, st, a);  // v1: weights 1 at run time
+  else ok = launch_accumulate<kModeHessian>(v, tt, C, grid, st, a);
+  if (!ok) {  // never silently: a missing launch would leave stale partial sums and an unposted board slot behind
+    ctx->last_error = "no iteration kernel is instantiated for mode " + std::to_string(mode) + " / robust function " +
+                      std::to_string(a.robust_type) + " / " + std::to_string(C) + " channels" + (a.u8 ? " / uint8 storage" : "");
+    return ICA_EINVAL_ARG;
+  }
+  return ICA_OK;
 }
 
 // Host side of the launch-sizing board: wait until the kernel of an earlier iteration has posted its
@@ -734,7 +743,7 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const void* I1v, co
     const bool l2_fold_hessian = !robust && ctx->fold_hessian;
     if (!robust && !l2_fold_hessian) {
       la.act_list = nullptr; la.act_count = nullptr; la.host_slot = nullptr;
-      launch_accumulate_mode(ctx, kModeHessian, tt, C, dim3(g[s].tiles, B), st, la);
+      ICA_TRY(launch_accumulate_mode(ctx, kModeHessian, tt, C, dim3(g[s].tiles, B), st, la));
       hipLaunchKernelGGL(ica_setup_solve_kernel, dim3(B), dim3(kSolveThreads), 0, st, la.partials, g[s].tiles, n,
                          ctx->hinv.as<double>());
     }
@@ -786,7 +795,7 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const void* I1v, co
       sa.invert_h = robust || first_l2;  // the solve inverts the H it receives ...
       sa.store_hinv = first_l2;          // ... and keeps the inverse for the later L2 iterations
       la.robust_type = first_l2 ? (int)ICA_QUADRATIC : pr->robust_type;
-      launch_accumulate_mode(ctx, robust ? kModeRobust : first_l2 ? kModeL2First : kModeL2, tt, C, dim3(lg.tiles, nb), st, la);
+      ICA_TRY(launch_accumulate_mode(ctx, robust ? kModeRobust : first_l2 ? kModeL2First : kModeL2, tt, C, dim3(lg.tiles, nb), st, la));
       if (ctx->profiling) {
         ICA_TRY(next_event(&e1));
         ICA_HIP(ctx, hipEventRecord(ctx->ev_pool[e1], st));
@@ -934,14 +943,14 @@ int ica_op_normal_equations_dev(ica_ctx* ctx, const ica_problem* pr, const void*
   la.n_pairs = B;
   la.act_list = nullptr; la.act_count = nullptr;
   if (robust) {
-    launch_accumulate_mode(ctx, kModeRobust, tt, C, dim3(g[0].tiles, B), ctx->stream, la);
+    ICA_TRY(launch_accumulate_mode(ctx, kModeRobust, tt, C, dim3(g[0].tiles, B), ctx->stream, la));
     hipLaunchKernelGGL(ica_gather_normal_equations_kernel, dim3(B), dim3(kSolveThreads), 0, ctx->stream, la.partials, g[0].tiles, n,
                        B, 1, 1, (const double*)nullptr, H_out, b_out);
   } else {
-    launch_accumulate_mode(ctx, kModeHessian, tt, C, dim3(g[0].tiles, B), ctx->stream, la);
+    ICA_TRY(launch_accumulate_mode(ctx, kModeHessian, tt, C, dim3(g[0].tiles, B), ctx->stream, la));
     hipLaunchKernelGGL(ica_gather_normal_equations_kernel, dim3(B), dim3(kSolveThreads), 0, ctx->stream, la.partials, g[0].tiles, n,
                        B, 0, 1, (const double*)nullptr, H_out, b_out);
-    launch_accumulate_mode(ctx, kModeL2, tt, C, dim3(g[0].tiles, B), ctx->stream, la);
+    ICA_TRY(launch_accumulate_mode(ctx, kModeL2, tt, C, dim3(g[0].tiles, B), ctx->stream, la));
     hipLaunchKernelGGL(ica_gather_normal_equations_kernel, dim3(B), dim3(kSolveThreads), 0, ctx->stream, la.partials, g[0].tiles, n,
                        B, 1, 0, (const double*)nullptr, H_out, b_out);
   }

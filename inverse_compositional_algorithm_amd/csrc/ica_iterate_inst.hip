@@ -22,7 +22,7 @@ void launch_c(int channels, unsigned blocks, hipStream_t st, const LevelArgs& a)
 }
 
 template <int TT>
-void launch_tt(int mode, int channels, int robust_type, unsigned blocks, hipStream_t st, const LevelArgs& a) {
+bool launch_tt(int mode, int channels, int robust_type, unsigned blocks, hipStream_t st, const LevelArgs& a) {
   switch (mode) {
     case kModeL2: launch_c<TT, kModeL2, ICA_QUADRATIC>(channels, blocks, st, a); break;
     case kModeL2First: launch_c<TT, kModeL2First, ICA_QUADRATIC>(channels, blocks, st, a); break;
@@ -34,18 +34,19 @@ void launch_tt(int mode, int channels, int robust_type, unsigned blocks, hipStre
         case ICA_GERMAN_MCCLURE: launch_c<TT, kModeRobust, ICA_GERMAN_MCCLURE>(channels, blocks, st, a); break;
         case ICA_LORENTZIAN: launch_c<TT, kModeRobust, ICA_LORENTZIAN>(channels, blocks, st, a); break;
         case ICA_CHARBONNIER: launch_c<TT, kModeRobust, ICA_CHARBONNIER>(channels, blocks, st, a); break;
-        default: break;  // QUADRATIC never takes the robust schedule (ica_solve_batch_dev)
+        default: return false;  // QUADRATIC has no robust instantiation: the caller reports it (nothing was launched)
       }
   }
+  return true;
 }
 
 }  // namespace
 
 #define ICA_CAT2(a, b) a##b
 #define ICA_CAT(a, b) ICA_CAT2(a, b)
-void ICA_CAT(launch_iterate_tt, ICA_INST_TT)(int mode, int channels, int robust_type, unsigned blocks, hipStream_t st,
+bool ICA_CAT(launch_iterate_tt, ICA_INST_TT)(int mode, int channels, int robust_type, unsigned blocks, hipStream_t st,
                                              const LevelArgs& a) {
-  launch_tt<ICA_INST_TT>(mode, channels, robust_type, blocks, st, a);
+  return launch_tt<ICA_INST_TT>(mode, channels, robust_type, blocks, st, a);
 }
 
 }  // namespace ica

@@ -10,20 +10,21 @@ namespace ica {
 
 // mode: kModeL2 / kModeRobust / kModeHessian / kModeL2First; channels 1 or 3; robust_type: the ICA_* error function
 // (used by kModeRobust only: a template argument of the kernel).  `blocks` = 1-D grid (see launch_iterate).
-void launch_iterate_tt1(int mode, int channels, int robust_type, unsigned blocks, hipStream_t st, const LevelArgs& a);
-void launch_iterate_tt2(int mode, int channels, int robust_type, unsigned blocks, hipStream_t st, const LevelArgs& a);
-void launch_iterate_tt3(int mode, int channels, int robust_type, unsigned blocks, hipStream_t st, const LevelArgs& a);
-void launch_iterate_tt4(int mode, int channels, int robust_type, unsigned blocks, hipStream_t st, const LevelArgs& a);
-void launch_iterate_tt5(int mode, int channels, int robust_type, unsigned blocks, hipStream_t st, const LevelArgs& a);
+bool launch_iterate_tt1(int mode, int channels, int robust_type, unsigned blocks, hipStream_t st, const LevelArgs& a);
+bool launch_iterate_tt2(int mode, int channels, int robust_type, unsigned blocks, hipStream_t st, const LevelArgs& a);
+bool launch_iterate_tt3(int mode, int channels, int robust_type, unsigned blocks, hipStream_t st, const LevelArgs& a);
+bool launch_iterate_tt4(int mode, int channels, int robust_type, unsigned blocks, hipStream_t st, const LevelArgs& a);
+bool launch_iterate_tt5(int mode, int channels, int robust_type, unsigned blocks, hipStream_t st, const LevelArgs& a);
 
-inline void launch_iterate(int tt, int mode, int channels, int robust_type, unsigned blocks, hipStream_t st,
+// false: no kernel is instantiated for this combination and nothing was launched
+inline bool launch_iterate(int tt, int mode, int channels, int robust_type, unsigned blocks, hipStream_t st,
                            const LevelArgs& a) {
   switch (tt) {
-    case ICA_TRANSLATION: launch_iterate_tt1(mode, channels, robust_type, blocks, st, a); break;
-    case ICA_EUCLIDEAN: launch_iterate_tt2(mode, channels, robust_type, blocks, st, a); break;
-    case ICA_SIMILARITY: launch_iterate_tt3(mode, channels, robust_type, blocks, st, a); break;
-    case ICA_AFFINITY: launch_iterate_tt4(mode, channels, robust_type, blocks, st, a); break;
-    default: launch_iterate_tt5(mode, channels, robust_type, blocks, st, a); break;
+    case ICA_TRANSLATION: return launch_iterate_tt1(mode, channels, robust_type, blocks, st, a);
+    case ICA_EUCLIDEAN: return launch_iterate_tt2(mode, channels, robust_type, blocks, st, a);
+    case ICA_SIMILARITY: return launch_iterate_tt3(mode, channels, robust_type, blocks, st, a);
+    case ICA_AFFINITY: return launch_iterate_tt4(mode, channels, robust_type, blocks, st, a);
+    default: return launch_iterate_tt5(mode, channels, robust_type, blocks, st, a);
   }
 }
 

@@ -1042,10 +1042,11 @@ __global__ __launch_bounds__(kBlock) void ica_resample_clip_kernel(float* __rest
 // Generic banded pass for downsampling factors the tiled passes are not sized for (a window of 16 outputs wider than
 // kVWin input rows, or a 64-output row tile that does not fit the LDS): one thread per output element, taps straight
 // from memory.  Slow and only reachable with nu below ~0.12, which the reference accepts like any other value.
+// (The vertical pass reads the level's own storage, float32 or uint8.)
 // VERTICAL: in [planes][n_in][W] -> out [planes][n_out][W].  Otherwise: in [planes][H][n_in] -> out [planes][H][n_out],
 // clipped to the pair's range (the horizontal pass is the last step of a pyramid level).
-template <bool VERTICAL>
-__global__ __launch_bounds__(kBlock) void ica_resample_generic_kernel(const float* __restrict__ in, float* __restrict__ out,
+template <bool VERTICAL, class TIn = float>
+__global__ __launch_bounds__(kBlock) void ica_resample_generic_kernel(const TIn* __restrict__ in, float* __restrict__ out,
                                                                       int channels, int other, BandOp op,
                                                                       const float* __restrict__ minmax) {
   const int pl = blockIdx.z;
@@ -1054,16 +1055,16 @@ __global__ __launch_bounds__(kBlock) void ica_resample_generic_kernel(const floa
   if (VERTICAL) {
     if (x >= other) return;
     const int j0 = op.start[y];
-    const float* q = in + ((size_t)pl * op.n_in + j0) * other + x;
+    const TIn* q = in + ((size_t)pl * op.n_in + j0) * other + x;
     float acc = 0.f;
-    for (int k = 0; k < op.K && j0 + k < op.n_in; ++k) acc = fmaf(op.wT[(size_t)k * op.n_out + y], q[(size_t)k * other], acc);
+    for (int k = 0; k < op.K && j0 + k < op.n_in; ++k) acc = fmaf(op.wT[(size_t)k * op.n_out + y], (float)q[(size_t)k * other], acc);
     out[((size_t)pl * op.n_out + y) * other + x] = acc;
   } else {
     if (x >= op.n_out) return;
     const int j0 = op.start[x];
-    const float* q = in + ((size_t)pl * other + y) * op.n_in + j0;
+    const TIn* q = in + ((size_t)pl * other + y) * op.n_in + j0;
     float acc = 0.f;
-    for (int k = 0; k < op.K && j0 + k < op.n_in; ++k) acc = fmaf(op.wT[(size_t)k * op.n_out + x], q[k], acc);
+    for (int k = 0; k < op.K && j0 + k < op.n_in; ++k) acc = fmaf(op.wT[(size_t)k * op.n_out + x], (float)q[k], acc);
     const int pair = pl / channels;
     out[((size_t)pl * other + y) * op.n_out + x] = fminf(fmaxf(acc, minmax[pair * 2]), minmax[pair * 2 + 1]);
   }

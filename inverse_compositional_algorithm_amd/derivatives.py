@@ -10,25 +10,28 @@ from .transformation import TransformType, _tt
 
 
 def _eng():
-    from .inverse_compositional_algorithm import _engine
-    return _engine()
+    from .inverse_compositional_algorithm import _use_engine
+    return _use_engine()
 
 
 def jacobian(transform_type: TransformType, nx: int, ny: int) -> np.ndarray:
     """reference: derivatives.py:7-70 -- (ny, nx, 2 * nparams): x row of the Jacobian first, then the y row."""
-    return _eng().ref_jacobian(_tt(transform_type), nx, ny)
+    with _eng() as eng:
+        return eng.ref_jacobian(_tt(transform_type), nx, ny)
 
 
 def hessian(DIJ: np.ndarray) -> np.ndarray:
     """reference: derivatives.py:73-89 -- sum of DIJ^T DIJ over pixels and channels; non-finite entries count as 0."""
     DIJ = np.asarray(DIJ, dtype=np.float64)
-    return _eng().ref_normal(DIJ)[0]
+    with _eng() as eng:
+        return eng.ref_normal(DIJ)[0]
 
 
 def hessian_robust(DIJ: np.ndarray, rho: np.ndarray, nparams: int) -> np.ndarray:
     """reference: derivatives.py:91-107 -- the same sum weighted by rho (ny, nx)."""
     DIJ = np.asarray(DIJ, dtype=np.float64)
-    return _eng().ref_normal(DIJ, rho=np.asarray(rho, dtype=np.float64))[0]
+    with _eng() as eng:
+        return eng.ref_normal(DIJ, rho=np.asarray(rho, dtype=np.float64))[0]
 
 
 def inverse_hessian(H: np.ndarray, nparams: int) -> np.ndarray:

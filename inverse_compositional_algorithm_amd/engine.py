@@ -210,8 +210,21 @@ class IcaEngine:
         check(self.lib.ica_op_ref_jacobian_dev(self.ctx, int(transform_type), int(nx), int(ny), _ptr(J)), self.ctx)
         return J.cpu().numpy()
 
+    @staticmethod
+    def _want_shape(name: str, a, shape) -> None:
+        """The reference's NumPy code rejects mismatched operands with a broadcast / index error; raw device pointers
+        would read out of bounds instead, so the shapes are checked here."""
+        import numpy as np
+        if tuple(np.shape(a)) != tuple(shape):
+            raise ValueError(f"{name} has shape {tuple(np.shape(a))}, expected {tuple(shape)}")
+
     def ref_steepest_descent(self, Ix, Iy, J, nparams: int):
+        import numpy as np
+        if np.ndim(Ix) != 3:
+            raise ValueError("Ix and Iy must have shape (ny, nx, nz)")
         ny, nx, nz = Ix.shape
+        self._want_shape("Iy", Iy, (ny, nx, nz))
+        self._want_shape("J", J, (ny, nx, 2 * int(nparams)))
         DIJ = torch.zeros(ny, nx, nz, int(nparams), dtype=torch.float64, device=self.device)
         a, b, c = self._f64(Ix), self._f64(Iy), self._f64(J)
         self._bind_stream()
@@ -220,7 +233,16 @@ class IcaEngine:
         return DIJ.cpu().numpy()
 
     def ref_normal(self, DIJ, DI=None, rho=None, want_h=True, want_b=False):
+        import numpy as np
+        if np.ndim(DIJ) != 4:
+            raise ValueError("DIJ must have shape (ny, nx, nz, nparams)")
         ny, nx, nz, n = DIJ.shape
+        if n > 8:
+            raise ValueError("at most 8 parameters")
+        if DI is not None:
+            self._want_shape("DI", DI, (ny, nx, nz))
+        if rho is not None:
+            self._want_shape("rho", rho, (ny, nx))
         d = self._f64(DIJ)
         di = self._f64(DI) if DI is not None else None
         r = self._f64(rho) if rho is not None else None
@@ -242,6 +264,9 @@ class IcaEngine:
         return out.cpu().numpy().reshape(np.shape(t2))
 
     def ref_robust_error(self, DI, lambda_: float, robust_type: int):
+        import numpy as np
+        if np.ndim(DI) != 3:
+            raise ValueError("DI must have shape (ny, nx, nz)")
         ny, nx, nz = DI.shape
         d = self._f64(DI)
         rho = torch.zeros(ny, nx, dtype=torch.float64, device=self.device)

@@ -18,8 +18,8 @@ class RobustErrorFunctionType(Enum):
 
 
 def _eng():
-    from .inverse_compositional_algorithm import _engine
-    return _engine()
+    from .inverse_compositional_algorithm import _use_engine
+    return _use_engine()
 
 
 def _rt(type_) -> int:
@@ -38,23 +38,27 @@ def _rt(type_) -> int:
 def rhop(t2, lambda_: float, type_) -> np.ndarray:
     """reference: image_optimisation.py:16-53.  TRUNCATED_QUADRATIC is evaluated element-wise (the reference's
     ``if t2 < lambda2`` raises on arrays, :40)."""
-    return _eng().ref_rhop(np.asarray(t2, dtype=np.float64), lambda_, _rt(type_))
+    with _eng() as eng:
+        return eng.ref_rhop(np.asarray(t2, dtype=np.float64), lambda_, _rt(type_))
 
 
 def robust_error_function(DI: np.ndarray, lambda_: float, type_) -> np.ndarray:
     """reference: image_optimisation.py:56-78 -- rho'(sum over channels of finite(DI)^2), (ny, nx)."""
-    return _eng().ref_robust_error(np.asarray(DI, dtype=np.float64), lambda_, _rt(type_))
+    with _eng() as eng:
+        return eng.ref_robust_error(np.asarray(DI, dtype=np.float64), lambda_, _rt(type_))
 
 
 def independent_vector(DIJ: np.ndarray, DI: np.ndarray, nparams: int) -> np.ndarray:
     """reference: image_optimisation.py:82-110 -- b = sum DIJ^T DI; non-finite entries count as 0."""
-    return _eng().ref_normal(np.asarray(DIJ, dtype=np.float64), DI=np.asarray(DI, dtype=np.float64), want_h=False, want_b=True)[1]
+    with _eng() as eng:
+        return eng.ref_normal(np.asarray(DIJ, dtype=np.float64), DI=np.asarray(DI, dtype=np.float64), want_h=False, want_b=True)[1]
 
 
 def independent_vector_robust(DIJ: np.ndarray, DI: np.ndarray, rho: np.ndarray, nparams: int) -> np.ndarray:
     """reference: image_optimisation.py:113-143 -- b = sum rho * DIJ^T DI."""
-    return _eng().ref_normal(np.asarray(DIJ, dtype=np.float64), DI=np.asarray(DI, dtype=np.float64),
-                             rho=np.asarray(rho, dtype=np.float64), want_h=False, want_b=True)[1]
+    with _eng() as eng:
+        return eng.ref_normal(np.asarray(DIJ, dtype=np.float64), DI=np.asarray(DI, dtype=np.float64),
+                              rho=np.asarray(rho, dtype=np.float64), want_h=False, want_b=True)[1]
 
 
 def parametric_solve(H_1: np.ndarray, b: np.ndarray, nparams: int):
@@ -68,4 +72,5 @@ def steepest_descent_images(Ix: np.ndarray, Iy: np.ndarray, J: np.ndarray, npara
     Ix, Iy = np.asarray(Ix, dtype=np.float64), np.asarray(Iy, dtype=np.float64)
     if Ix.shape != Iy.shape:
         raise ValueError("Ix and Iy must have the same dimensions")
-    return _eng().ref_steepest_descent(Ix, Iy, np.asarray(J, dtype=np.float64), int(nparams))
+    with _eng() as eng:
+        return eng.ref_steepest_descent(Ix, Iy, np.asarray(J, dtype=np.float64), int(nparams))

@@ -6,6 +6,9 @@ reference: inverse_compositional_algorithm.py:17-133, :135-261, :264-374
 """
 from __future__ import annotations
 
+import contextlib
+import threading
+
 import numpy as np
 import torch
 
@@ -15,15 +18,41 @@ from .image_optimisation import RobustErrorFunctionType
 from .transformation import TransformType
 
 _ENGINES: dict = {}
+_ENGINES_LOCK = threading.Lock()
+_DEVICE = 0
+_FINITE_MSG = "I1 and I2 must contain finite values only"
 _RGB_MSG = "I1 and I2 must be RGB images with channels in the last dimension"
 _DIM_MSG = "I1 and I2 must have the same dimensions"
 _TOL_MSG = "TOL must be positive and very small (less than 0.01)"
 
 
-def _engine(device: int = 0) -> IcaEngine:
-    if device not in _ENGINES:
-        _ENGINES[device] = IcaEngine(device)
-    return _ENGINES[device]
+def set_device(device: int) -> None:
+    """GPU the three drop-in functions run on (default 0).  The reference has no such notion; a process that drives
+    several GPUs calls this once per worker thread's turn, or uses engine.IcaEngine / sharding.py directly."""
+    global _DEVICE
+    _DEVICE = int(device)
+
+
+def _engine_entry(device: int = None):
+    device = _DEVICE if device is None else int(device)
+    with _ENGINES_LOCK:
+        if device not in _ENGINES:
+            _ENGINES[device] = (IcaEngine(device), threading.RLock())
+        return _ENGINES[device]
+
+
+def _engine(device: int = None) -> IcaEngine:
+    """The engine of one GPU (not locked: for single-threaded callers such as the tests)."""
+    return _engine_entry(device)[0]
+
+
+@contextlib.contextmanager
+def _use_engine(device: int = None):
+    """The engine of one GPU, held for the duration of the block.  A library context is single-threaded
+    (include/ica_hip.h), so concurrent callers of the drop-in functions are serialised per device."""
+    eng, lock = _engine_entry(device)
+    with lock:
+        yield eng
 
 
 def _to_device(img: np.ndarray, eng: IcaEngine, u8: bool = False) -> torch.Tensor:
@@ -66,17 +95,25 @@ def _run(I1, I2, p, transform_type, TOL, robust_type, lambda_, nanifoutside, del
         raise ValueError(_TOL_MSG)                                     # ref :59-60
     if not 1 <= I1.shape[2] <= 4:
         raise ValueError(_RGB_MSG)  # the library is built for 1..4 channels (differences)
+    # Non-finite pixels: the reference zero-fills non-finite residuals and derivatives element by element (image_optimisation.py:99,
+    # derivatives.py:84) but clips the warp to [I2.min(), I2.max()], which a single NaN turns into NaN bounds and an
+    # all-NaN warp: its result on such inputs is an accident, not a contract.  The kernels' fast path does no per-pixel
+    # finiteness tests, so such inputs are refused here, loudly (differences).
+    for img in (I1, I2):
+        if img.dtype.kind == "f" and not np.isfinite(img).all():
+            raise ValueError(_FINITE_MSG)
     tt = TransformType(transform_type) if not isinstance(transform_type, TransformType) else transform_type
     rt = RobustErrorFunctionType(robust_type) if not isinstance(robust_type, RobustErrorFunctionType) else robust_type
     n = tt.nparams()
-    eng = _engine()
+    eng, lock = _engine_entry()
     H, W, C = I1.shape
     prob = eng.problem(1, H, W, C, tt.value, rt.value, nscales, nu, TOL, float(lambda_), bool(nanifoutside is True),
                        int(delta), cts.MAX_ITER)
     p0 = torch.as_tensor(np.asarray(p, dtype=np.float64)[:n]).reshape(1, n)
     u8 = I1.dtype == np.uint8 and I2.dtype == np.uint8 and C in (1, 3)
-    res = eng.solve(_to_device(I1, eng, u8), _to_device(I2, eng, u8), prob, p0=p0, want_images=True,
-                    want_trace=bool(verbose))
+    with lock:
+        res = eng.solve(_to_device(I1, eng, u8), _to_device(I2, eng, u8), prob, p0=p0, want_images=True,
+                        want_trace=bool(verbose))
     p_out = res.p[0, :n].cpu().numpy()
     error = float(res.error[0].cpu())
     if verbose:

@@ -16,6 +16,8 @@ Tensors already on the engine's GPU are used in place (`channels_first=True` ski
 """
 from typing import Optional, Sequence
 
+import threading
+
 import torch
 
 from . import constants as cts
@@ -24,12 +26,15 @@ from .image_optimisation import RobustErrorFunctionType
 from .transformation import TransformType
 
 _engines = {}
+_engines_lock = threading.Lock()
 
 
-def _engine(device: int) -> IcaEngine:
-    if device not in _engines:
-        _engines[device] = IcaEngine(device)
-    return _engines[device]
+def _engine(device: int):
+    """One engine (= one library context, single-threaded by contract) per GPU, with the lock that serialises its users."""
+    with _engines_lock:
+        if device not in _engines:
+            _engines[device] = (IcaEngine(device), threading.Lock())
+        return _engines[device]
 
 
 class _IcaLayer(torch.nn.Module):
@@ -51,7 +56,10 @@ class _IcaLayer(torch.nn.Module):
         x = torch.as_tensor(x)
         if x.dim() != 4:
             raise ValueError("I1 and I2 must be batches of images, (B, H, W, C)")
-        x = x.to(device=dev) if x.dtype == torch.uint8 else x.to(device=dev, dtype=torch.float32)  # 8-bit stays 8-bit
+        channels = x.shape[1] if self.channels_first else x.shape[3]
+        # 8-bit gray / RGB stays 8-bit in device memory (uint8 storage); the 2- and 4-channel kernel reads float32 only
+        keep_u8 = x.dtype == torch.uint8 and channels in (1, 3)
+        x = x.to(device=dev) if keep_u8 else x.to(device=dev, dtype=torch.float32)
         return x.contiguous() if self.channels_first else x.permute(0, 3, 1, 2).contiguous()
 
     def forward(self, inputs: Sequence[torch.Tensor], transform_type: Optional[TransformType] = None):
@@ -59,7 +67,7 @@ class _IcaLayer(torch.nn.Module):
             self.transform_type = transform_type
         if self.transform_type is None:
             raise ValueError("transform_type must be given to the constructor or to the call")
-        eng = _engine(self.device_index)
+        eng, lock = _engine(self.device_index)
         I1, I2 = self._planar(inputs[0], eng.device), self._planar(inputs[1], eng.device)
         if I1.shape != I2.shape:
             raise ValueError("I1 and I2 must have the same dimensions")
@@ -68,7 +76,8 @@ class _IcaLayer(torch.nn.Module):
         prob = eng.problem(B, H, W, C, int(self.transform_type.value), int(self.robust_type.value),
                            nscales=self.nscales, nu=self.nu, tol=self.TOL, lambda_=self.lambda_, delta=self.delta,
                            nanifoutside=self.nanifoutside, max_iter=self.max_iter)
-        res = eng.solve(I1, I2, prob, p0=p0, want_images=True)
+        with lock:
+            res = eng.solve(I1, I2, prob, p0=p0, want_images=True)
         self.last_niter = res.niter
         if self.verbose:
             nit = res.niter.sum(dim=1)

@@ -120,7 +120,7 @@ def transform_image(image, transformation_type, gt):
     the transform `gt`, zeros outside, float64 (H, W, C) result.  Runs on the GPU (ica_op_transform_image_dev)."""
     import torch
 
-    from .inverse_compositional_algorithm import _engine
+    from .inverse_compositional_algorithm import _use_engine
     image = np.asarray(image)
     if image.dtype != np.float64:
         image = image.astype(np.float64)
@@ -136,7 +136,7 @@ def transform_image(image, transformation_type, gt):
         M = params2matrix(gt, 1)
     else:
         M = params2matrix(gt, t)
-    eng = _engine()
     x = np.ascontiguousarray(np.moveaxis(image.astype(np.float32), 2, 0))[None]
-    out = eng.transform_image(torch.from_numpy(x).to(eng.device), np.linalg.inv(M)[None])
-    return np.moveaxis(out[0].cpu().numpy().astype(np.float64), 0, 2)
+    with _use_engine() as eng:
+        out = eng.transform_image(torch.from_numpy(x).to(eng.device), np.linalg.inv(M)[None])
+        return np.moveaxis(out[0].cpu().numpy().astype(np.float64), 0, 2)

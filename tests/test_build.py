@@ -29,8 +29,19 @@ def test_an_edit_to_any_source_or_flag_makes_the_library_stale(tmp_path, monkeyp
     monkeypatch.delenv("ICA_EXTRA_FLAGS", raising=False)
     assert b.is_stale()  # no library yet
     (here / "libica_hip.so").write_bytes(b"not a real library")
-    (here / "libica_hip.so.stamp").write_text(b.fingerprint() + "\n")
+    (here / "libica_hip.so.stamp").write_text(b.fingerprint() + "\n" + b.lib_digest() + "\n")
     assert not b.is_stale()
+    # a library that some other tool overwrote (a partial link, a truncated copy) is stale although no source changed
+    (here / "libica_hip.so").write_bytes(b"not a real libr")
+    assert b.is_stale()
+    (here / "libica_hip.so").write_bytes(b"a foreign file of another size")
+    assert b.is_stale()
+    (here / "libica_hip.so").write_bytes(b"not a real library")
+    assert not b.is_stale()
+    # a stamp from before the digest was recorded (one line) does not vouch for the binary
+    (here / "libica_hip.so.stamp").write_text(b.fingerprint() + "\n")
+    assert b.is_stale()
+    (here / "libica_hip.so.stamp").write_text(b.fingerprint() + "\n" + b.lib_digest() + "\n")
     for name in sorted(os.listdir(here / "csrc")) + ["../../include/ica_hip.h"]:
         path = (here / "csrc" / name).resolve()
         old = path.read_bytes()
@@ -40,3 +51,15 @@ def test_an_edit_to_any_source_or_flag_makes_the_library_stale(tmp_path, monkeyp
         assert not b.is_stale()
     monkeypatch.setenv("ICA_EXTRA_FLAGS", "-DICA_ABLATE=1")
     assert b.is_stale()  # other flags, other binary
+
+
+def test_no_tool_names_the_product_library():
+    """Experiment and analysis scripts build into tools/abl/ or a scratch directory; none of them may write to (or even
+    name) the product library: a partial link left there once shipped a broken binary to the GPU box."""
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(b.__file__))), "tools")
+    for root, _, files in os.walk(tools):
+        for name in files:
+            if not name.endswith((".py", ".sh", ".hip")):
+                continue
+            with open(os.path.join(root, name), errors="replace") as fh:
+                assert "libica_hip.so" not in fh.read(), f"tools/{name} names the product library"

@@ -40,7 +40,7 @@ def test_struct_layout_matches_header(lib):
 
 
 def test_host_only_entry_points(lib):
-    assert lib.ica_version() == 1
+    assert lib.ica_version() == 3
     assert [lib.ica_nparams(t) for t in (1, 2, 3, 4, 5)] == [2, 3, 4, 6, 8]  # transformation.py:16-32
     assert lib.ica_nparams(0) < 0 and lib.ica_nparams(6) < 0
     w, h = C.c_int(), C.c_int()

@@ -1,10 +1,14 @@
 #!/usr/bin/env python3
-"""Compile libica_hip.so and print VGPR / occupancy / LDS per kernel (hipcc -Rpass-analysis=kernel-resource-usage)."""
-import os, re, subprocess, sys
+"""usage: kres.py [kernel name substring] [csrc file] [extra hipcc flags, e.g. -DICA_INST_TT=5]
+Compile one translation unit of the library into a scratch directory and print VGPR / occupancy / LDS per kernel (hipcc -Rpass-analysis=kernel-resource-usage)."""
+import os, re, subprocess, sys, tempfile
 here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "inverse_compositional_algorithm_amd")
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", os.path.join(here, "libica_hip.so"),
-       os.path.join(here, "csrc", "ica_api.hip"), "-Rpass-analysis=kernel-resource-usage"]
-out = subprocess.run(cmd, capture_output=True, text=True)
+# (the object goes to a scratch directory: a tool must never write to the product library's path)
+src = os.path.join(here, "csrc", sys.argv[2] if len(sys.argv) > 2 else "ica_api.hip")
+with tempfile.TemporaryDirectory(prefix="ica_kres_") as tmp:
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-o", os.path.join(tmp, "kres.o"),
+           src, "-Rpass-analysis=kernel-resource-usage"] + sys.argv[3:]
+    out = subprocess.run(cmd, capture_output=True, text=True)
 txt = out.stderr
 if out.returncode:
     print("\n".join(l for l in txt.splitlines() if "error" in l or "note:" in l)[:4000]); sys.exit(1)
