@@ -69,3 +69,17 @@ def test_layer_validation_and_batch_independence():
     p_all = layer([torch.from_numpy(I1), torch.from_numpy(I2)])[0]
     p_one = layer([torch.from_numpy(I1[2:3]), torch.from_numpy(I2[2:3])])[0]   # per-pair convergence: no batch coupling
     np.testing.assert_allclose(p_one[0].cpu().numpy(), p_all[2].cpu().numpy(), rtol=1e-6, atol=1e-10)
+
+
+@pytest.mark.parametrize("C", [1, 2, 3, 4])
+def test_uint8_batches_of_any_channel_count(C):
+    """8-bit gray / RGB batches stay 8-bit on the device (uint8 storage); 2- and 4-channel ones are widened to float32,
+    which is what their kernel reads.  Either way the result is the float32 batch's."""
+    from inverse_compositional_algorithm_amd.layers import RobustInverseCompositional
+    B, H, W = 2, 64, 80
+    I1, I2 = batch(950 + C, B, H, W, C, 1, False)
+    layer = RobustInverseCompositional(robust_type=R.CHARBONNIER, delta=4, verbose=False, transform_type=T.TRANSLATION)
+    pf = layer([torch.from_numpy(I1), torch.from_numpy(I2)])[0]
+    pu = layer([torch.from_numpy(I1.astype(np.uint8)), torch.from_numpy(I2.astype(np.uint8))])[0]
+    assert np.array_equal(I1, I1.astype(np.uint8).astype(I1.dtype))  # the synthetic images hold 8-bit values
+    np.testing.assert_array_equal(pf.cpu().numpy(), pu.cpu().numpy())

@@ -349,15 +349,17 @@ def test_alternative_schedules_give_the_same_iterates(eng):
     """The library's optional code paths are alternative schedules of the same arithmetic: a separate Hessian pass per
     level instead of the folded first iteration (ICA_SEPARATE_HESSIAN), the direct-gather iteration kernel
     (ICA_ACCUM=1), 16-row tiles everywhere (ICA_MAX_TILE_H).  Identical iteration counts, parameters equal to rounding -- on an L2 and on a robust
-    problem (the options are read when a context is created, hence one process per setting)."""
+    problem, with float32 and with uint8 images (the options are read when a context is created, hence one process per setting;
+    with ICA_ACCUM=1 a uint8 level still runs the LDS-staged kernel, and its first L2 iteration must launch it)."""
     import os
     import subprocess
     import sys
     code = ("import numpy as np, torch, sys; sys.path.insert(0, %r);"
             "from inverse_compositional_algorithm_amd.engine import IcaEngine;"
             "e = IcaEngine(0); out = [];\n"
-            "for t, r in ((5, 3), (4, 0)):\n"
+            "for t, r, u8 in ((5, 3, 0), (4, 0, 0), (5, 3, 1), (4, 0, 1)):\n"
             "    I1, I2, _ = e.make_batch(5, 16, 128, 160, 1, t, robust_clutter=(r != 0))\n"
+            "    if u8: I1, I2 = I1.to(torch.uint8), I2.to(torch.uint8)\n"
             "    q = e.solve(I1, I2, e.problem(16, 128, 160, 1, t, r, nscales=2, delta=5))\n"
             "    out += [q.p.cpu().numpy().ravel(), q.niter.cpu().numpy().ravel().astype(float)]\n"
             "np.save(sys.argv[1], np.concatenate(out))"
@@ -368,9 +370,11 @@ def test_alternative_schedules_give_the_same_iterates(eng):
         path = f"/tmp/ica_schedule_{name}.npy"
         subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, **extra), timeout=300)
         outs[name] = np.load(path)
-    ref = outs.pop("default").reshape(2, -1)  # per problem: 16 x 8 parameters, then 16 x 2 iteration counts
+    # per problem (L2 and robust, float32 and uint8 storage): 16 x 8 parameters, then 16 x 2 iteration counts
+    ref = outs.pop("default").reshape(4, -1)
+    np.testing.assert_array_equal(ref[:2], ref[2:])  # uint8 storage: the float32 storage's results, bit for bit
     for name, o in outs.items():
-        o = o.reshape(2, -1)
+        o = o.reshape(4, -1)
         np.testing.assert_array_equal(o[:, 128:], ref[:, 128:], err_msg=name)                  # iteration counts
         # (the direct-gather kernel forms its per-pixel products in another order: fp32 rounding differs)
         tol = 1e-4 if name == "direct_gather" else 1e-6
@@ -617,3 +621,42 @@ def test_uint8_storage_rejects_what_it_does_not_cover(eng):
     assert e.value.status == -1  # 2- and 4-channel images are float32 only
     with pytest.raises(ValueError, match="same dtype"):
         eng.solve(x[:, :1].contiguous(), x[:, :1].float().contiguous(), eng.problem(1, 32, 32, 1, oc.TRANSLATION, 0))
+
+
+@pytest.mark.parametrize("nu", [0.1, 0.07])
+def test_uint8_storage_with_a_very_small_pyramid_factor(eng, nu):
+    """uint8 level-0 images through the generic pyramid pass (nu below ~0.12: a window of 16 outputs wider than the tiled
+    pass is sized for): the same results as float32 storage, like every other nu."""
+    B, H_, W_, C, t = 3, 200, 240, 1, oc.TRANSLATION
+    prs = [syn.make_pair(7300 + i, H_, W_, C, t) for i in range(B)]
+    f1, f2 = to_dev(eng, *[a for a, _, _ in prs]), to_dev(eng, *[b for _, b, _ in prs])
+    prob = eng.problem(B, H_, W_, C, t, oc.QUADRATIC, nscales=2, nu=nu, delta=2)
+    a = eng.solve(f1, f2, prob)
+    b = eng.solve(f1.to(torch.uint8), f2.to(torch.uint8), prob)
+    assert torch.equal(a.p, b.p) and torch.equal(a.niter, b.niter) and torch.equal(a.error, b.error)
+
+
+def test_a_pair_too_large_for_32_bit_offsets_is_refused(eng):
+    """One pair's planes are addressed through 32-bit buffer offsets: C * H * W * 4 bytes must stay below 2^31."""
+    from inverse_compositional_algorithm_amd._lib import IcaError
+    prob = eng.problem(1, 13400, 13400, 3, oc.TRANSLATION, 0)
+    import ctypes
+    from inverse_compositional_algorithm_amd._lib import check
+    with pytest.raises(IcaError) as e:  # the descriptor is refused before anything is allocated or launched
+        check(eng.lib.ica_prepare(eng.ctx, ctypes.byref(prob)), eng.ctx)
+    assert e.value.status == -1
+
+
+def test_operator_wrappers_check_shapes(eng):
+    """The reference's NumPy operators fail on mismatched operands; so do the wrappers (before any device access)."""
+    Ix = np.zeros((6, 7, 3))
+    with pytest.raises(ValueError):
+        eng.ref_steepest_descent(Ix, np.zeros((6, 7, 2)), np.zeros((6, 7, 4)), 2)
+    with pytest.raises(ValueError):
+        eng.ref_steepest_descent(Ix, Ix, np.zeros((6, 7, 6)), 2)   # J must be (ny, nx, 2 * nparams)
+    with pytest.raises(ValueError):
+        eng.ref_normal(np.zeros((6, 7, 3, 2)), DI=np.zeros((6, 7, 2)), want_b=True)
+    with pytest.raises(ValueError):
+        eng.ref_normal(np.zeros((6, 7, 3, 2)), rho=np.zeros((6, 6)))
+    with pytest.raises(ValueError):
+        eng.ref_robust_error(np.zeros((6, 7)), 5.0, 3)

@@ -83,6 +83,17 @@ def test_dropin_signatures_and_argument_errors():
         ica.robust_inverse_compositional_algorithm(rgb, rgb[:-1], np.zeros(6), T, 1e-3, R, 0., True, 5, False)
     with pytest.raises(ValueError, match="TOL must be positive and very small"):
         ica.inverse_compositional_algorithm(rgb, rgb, np.zeros(6), T, 0.01, True, 5, False)
+    # non-finite pixels: the reference's result on them is an accident of np.clip with NaN bounds (its residuals are
+    # zero-filled element by element, image_optimisation.py:99, but the warp is clipped to [I2.min(), I2.max()]); the
+    # drop-in refuses them by name instead of computing something else silently
+    bad = rgb.copy()
+    bad[3, 4, 1] = np.nan
+    for a, b_ in ((bad, rgb), (rgb, bad)):
+        with pytest.raises(ValueError, match="finite values only"):
+            ica.robust_inverse_compositional_algorithm(a, b_, np.zeros(6), T, 1e-3, R, 0., True, 5, False)
+    bad[3, 4, 1] = np.inf
+    with pytest.raises(ValueError, match="finite values only"):
+        ica.pyramidal_inverse_compositional_algorithm(rgb, bad, np.zeros(6), T, 2, 0.5, 1e-3, R, 0., True, 5, False)
 
 
 def test_synthetic_generator_is_deterministic():
