@@ -124,6 +124,11 @@ int ica_destroy(ica_ctx* ctx);
 int ica_set_stream(ica_ctx* ctx, void* hip_stream); /* NULL = default stream                        */
 int ica_synchronize(ica_ctx* ctx);
 int ica_set_profiling(ica_ctx* ctx, int on);       /* HIP events around every iteration-kernel launch */
+/* Measurement aid (no reference counterpart): ONE wave on this ctx's stream compares the shader clock counter
+ * (s_memtime) with the constant 100 MHz counter (s_memrealtime) for `duration_us` microseconds and returns the
+ * shader clock it saw, in GHz.  Run on a second ctx / stream while another ctx computes, it reports the clock the
+ * chip sustains UNDER THAT LOAD (the driver's sysfs reading does not track it).  Blocks until the wave is done. */
+int ica_op_shader_clock_dev(ica_ctx* ctx, int duration_us, double* ghz_out);
 int ica_nparams(int transform_type);   /* transformation.py:16-32; < 0 if unknown                    */
 /* zoom.py:8-22: level sizes, int(np.round(n*nu)) (round-half-even). */
 int ica_zoom_size(int width, int height, double nu, int* out_width, int* out_height);

@@ -49,6 +49,7 @@ _SIGNATURES = {
     "ica_set_stream": (C.c_int, [_P, _P]),
     "ica_synchronize": (C.c_int, [_P]),
     "ica_set_profiling": (C.c_int, [_P, C.c_int]),
+    "ica_op_shader_clock_dev": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double)]),
     "ica_nparams": (C.c_int, [C.c_int]),
     "ica_zoom_size": (C.c_int, [C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ica_prepare": (C.c_int, [_P, C.POINTER(Problem)]),

@@ -82,7 +82,7 @@ struct ica_ctx {
   // workspaces
   DevBuf pyr1[ICA_MAX_SCALES], pyr2[ICA_MAX_SCALES];  // levels >= 1
   DevBuf tmp_resample;                                // intermediate of the separable pyramid pass
-  DevBuf partials, hinv, p_prev, lambda_it, error, niter, lists, counts, count_hist, minmax, mm_part, mm_in, out_part;
+  DevBuf partials, hinv, p_prev, lambda_it, error, niter, lists, counts, count_hist, minmax, mm_part, mm_in, out_part, clock_probe;
   DevBuf scratch_p, ref_part;
   int* pinned_count = nullptr;   // one list's shard counters for synchronous reads + a [scales][max_iter] board the kernels post to
   int* board = nullptr;          // host pointer of the board (pinned, host-coherent)
@@ -100,7 +100,7 @@ struct ica_ctx {
     if (handover) (void)hipEventDestroy(handover);
     for (int i = 0; i < ICA_MAX_SCALES; ++i) { pyr1[i].release(); pyr2[i].release(); }
     DevBuf* all[] = {&tmp_resample, &partials, &hinv, &p_prev, &lambda_it, &error, &niter, &lists, &counts,
-                     &count_hist, &minmax, &mm_part, &mm_in, &out_part, &scratch_p, &ref_part};
+                     &count_hist, &minmax, &mm_part, &mm_in, &out_part, &scratch_p, &ref_part, &clock_probe};
     for (auto* b : all) b->release();
     if (pinned_count) (void)hipHostFree(pinned_count);
     if (board) (void)hipHostFree(board);
@@ -620,6 +620,33 @@ int ica_synchronize(ica_ctx* ctx) {
 int ica_set_profiling(ica_ctx* ctx, int on) {
   if (!ctx) return ICA_EINVAL_ARG;
   ctx->profiling = on != 0;
+  return ICA_OK;
+}
+
+// one wave: shader cycles (s_memtime) per tick of the constant 100 MHz counter (s_memrealtime) over `ticks` ticks
+__global__ void ica_shader_clock_kernel(long long ticks, unsigned long long* out) {
+  const long long r0 = wall_clock64(), c0 = clock64();
+  long long r1 = r0;
+  while (r1 - r0 < ticks) {
+    __builtin_amdgcn_s_sleep(32);
+    r1 = wall_clock64();
+  }
+  const long long c1 = clock64();
+  r1 = wall_clock64();
+  if (threadIdx.x == 0) { out[0] = (unsigned long long)(c1 - c0); out[1] = (unsigned long long)(r1 - r0); }
+}
+
+int ica_op_shader_clock_dev(ica_ctx* ctx, int duration_us, double* ghz_out) {
+  if (!ctx || !ghz_out || duration_us <= 0 || duration_us > 10000000) return ICA_EINVAL_ARG;
+  ICA_HIP(ctx, hipSetDevice(ctx->device));
+  ICA_HIP(ctx, ctx->clock_probe.ensure(2 * sizeof(unsigned long long)));
+  unsigned long long* d = ctx->clock_probe.as<unsigned long long>();
+  hipLaunchKernelGGL(ica_shader_clock_kernel, dim3(1), dim3(64), 0, ctx->stream, (long long)duration_us * 100, d);
+  ICA_HIP(ctx, hipGetLastError());
+  unsigned long long h[2] = {0, 0};
+  ICA_HIP(ctx, hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  ICA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *ghz_out = h[1] ? (double)h[0] / ((double)h[1] * 10.0) : 0.0;
   return ICA_OK;
 }
 

@@ -70,6 +70,15 @@ class IcaEngine:
     def synchronize(self):
         check(self.lib.ica_synchronize(self.ctx), self.ctx)
 
+    def shader_clock_ghz(self, duration_us: int = 20000) -> float:
+        """The shader clock one wave sees over `duration_us` (s_memtime against the constant 100 MHz counter), on this
+        engine's current stream: call it on a second engine / stream while another one computes to read the clock the
+        chip sustains under that load."""
+        self._bind_stream()
+        ghz = C.c_double(0.0)
+        check(self.lib.ica_op_shader_clock_dev(self.ctx, int(duration_us), C.byref(ghz)), self.ctx)
+        return float(ghz.value)
+
     @staticmethod
     def problem(batch, height, width, channels, transform_type, robust_type=0, nscales=1, nu=0.5, tol=1e-3,
                 lambda_=0.0, nanifoutside=True, delta=10, max_iter=MAX_ITER, flags=0, storage=0) -> Problem:

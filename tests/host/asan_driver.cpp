@@ -19,7 +19,7 @@
 #include "../../inverse_compositional_algorithm_amd/csrc/ica_iterate_launch.hpp"
 namespace ica {
 #define ICA_STUB(n) \
-  void launch_iterate_tt##n(int, int, int, unsigned, hipStream_t, const LevelArgs&) { std::abort(); }
+  bool launch_iterate_tt##n(int, int, int, unsigned, hipStream_t, const LevelArgs&) { std::abort(); }
 ICA_STUB(1) ICA_STUB(2) ICA_STUB(3) ICA_STUB(4) ICA_STUB(5)
 #undef ICA_STUB
 }  // namespace ica
@@ -72,6 +72,7 @@ int main() {
   CHECK(ica_solve_batch_dev(nullptr, &pr, &img, &img, p8, &err, nit, nullptr, nullptr, nullptr, nullptr) == ICA_EINVAL_ARG);
   CHECK(ica_solve_batch(nullptr, &pr, &img, &img, p8, &err, nit, nullptr, nullptr, nullptr, nullptr) == ICA_EINVAL_ARG);
   CHECK(ica_op_minmax_dev(nullptr, 1, 1, 1, 1, &img, &img) == ICA_EINVAL_ARG);
+  { double ghz = 0; CHECK(ica_op_shader_clock_dev(nullptr, 100, &ghz) == ICA_EINVAL_ARG); }
   CHECK(ica_op_warp_dev(nullptr, 1, 1, 8, 8, 1, &img, p8, nullptr, nullptr, &img, nullptr) == ICA_EINVAL_ARG);
   CHECK(ica_op_normal_equations_dev(nullptr, &pr, &img, &img, p8, nullptr, p8, p8) == ICA_EINVAL_ARG);
   CHECK(ica_op_solve_update_dev(nullptr, 1, 1, 0, p8, p8, p8, nullptr, nullptr) == ICA_EINVAL_ARG);
