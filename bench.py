@@ -61,14 +61,34 @@ def kernel_key(cfg):
     return f"<{cfg['transform']}, {1 if cfg['robust'] else 0}, {cfg['C']}, {cfg['robust']}>"
 
 
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
+
+
+def library_fingerprint():
+    """Source fingerprint of the library this process loaded (the build stamp's first line); None for an experiment
+    build selected with ICA_LIB, which has no stamp."""
+    if "ICA_LIB" in os.environ:
+        return None
+    try:
+        from inverse_compositional_algorithm_amd import build
+        return build.read_stamp()[0] or None
+    except Exception:
+        return None
+
+
 def measured_traffic(cfg):
     """HBM bytes / algorithmic bytes of one full-batch launch of this workload's iteration kernel, from the committed
-    PMC passes (profiles/r02_traffic.json, built by tools/pmc_traffic.sh from the raw rocprofv3 --pmc FETCH_SIZE CSVs
-    next to it; x1024 B, x2 gfx950 correction).  bench.py cannot collect PMC counters itself: the per-launch `traffic`
-    it reports is this measured ratio times the launch's algorithmic bytes; null when no pass exists for the kernel."""
+    PMC passes (profiles/r03_traffic.json, built by tools/pmc_traffic.sh from rocprofv3 --pmc FETCH_SIZE CSVs; x1024 B,
+    x2 gfx950 correction).  bench.py cannot collect PMC counters itself: the per-launch `traffic` it reports is this
+    measured ratio times the launch's algorithmic bytes -- and ONLY when the file was measured on the very library that is
+    loaded now (the file records the library's source fingerprint); after any change to the kernels it is null until
+    the counters have been collected again."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as fh:
-            e = json.load(fh)["kernels"][kernel_key(cfg)]
+        with open(TRAFFIC_FILE) as fh:
+            doc = json.load(fh)
+        if not doc.get("library_fingerprint") or doc["library_fingerprint"] != library_fingerprint():
+            return None, f"stale: {os.path.basename(TRAFFIC_FILE)} was measured on another build of the library"
+        e = doc["kernels"][kernel_key(cfg)]
         return float(e["fetch_bytes_over_algorithmic_bytes"]), e.get("source")
     except Exception:
         return None, None
@@ -268,7 +288,8 @@ def measure(args, info, sharding, cfg_id, steps, warmup, D, batch=0, storage="f3
     errors = []
     ns = cfg["nscales"]
     acc = dict(units=0, per_scale=[0] * ns, dom_ms=0.0, dom_bytes=0.0, dom_n=0, s0_ms=0.0, s0_bytes=0.0, s0_n=0,
-               first_ms=0.0, n_prof=0, res=None, latency=0.0)
+               first_ms=0.0, n_prof=0, res=None, latency=0.0, lvl_ms=[0.0] * ns, lvl_bytes=[0.0] * ns, lvl_n=[0] * ns,
+               lvl_units=[0] * ns, lvl_first_ms=[0.0] * ns, lvl_first_n=[0] * ns, lvl_wh=[(0, 0)] * ns)
 
     def run_steps(n_steps, timed):
         counter = iter(range(n_steps))
@@ -313,6 +334,14 @@ def measure(args, info, sharding, cfg_id, steps, warmup, D, batch=0, storage="f3
                             acc["s0_bytes"] += r.stats["iter_kernel_bytes"][0]
                             acc["s0_n"] += r.stats["iter_launches"][0]
                             acc["first_ms"] += sum(r.stats["first_kernel_ms"])
+                            for s in range(ns):
+                                acc["lvl_ms"][s] += r.stats["iter_kernel_ms"][s]
+                                acc["lvl_bytes"][s] += r.stats["iter_kernel_bytes"][s]
+                                acc["lvl_n"][s] += r.stats["iter_launches"][s]
+                                acc["lvl_units"][s] += r.stats["pair_iterations"][s]
+                                acc["lvl_first_ms"][s] += r.stats["first_kernel_ms"][s]
+                                acc["lvl_first_n"][s] += r.stats["first_launches"][s]
+                                acc["lvl_wh"][s] = tuple(r.stats["level_size"][s])
 
         if D == 1:
             worker(0)
@@ -328,11 +357,34 @@ def measure(args, info, sharding, cfg_id, steps, warmup, D, batch=0, storage="f3
     # the dominant kernel = the steady-state iteration kernel (one template instantiation), ALL its launches of the
     # event-bracketed steps at every pyramid scale -- the same set rocprofv3 --stats averages under that kernel's name
     run_steps(max(warmup, D if D > 1 else 0), timed=False)
+    # the shader clock the chip sustains under this load: one wave on a second context / stream compares s_memtime with
+    # the constant 100 MHz counter, 20 ms at a time, for as long as the timed region lasts (rank 0's GPU)
+    clock = dict(samples=[], stop=False)
+    probe = None
+    if os.environ.get("BENCH_CLOCK", "1") == "1":
+        probe_eng = IcaEngine(local)
+        probe_stream = torch.cuda.Stream(device=eng.device)
+
+        def probe_loop():
+            torch.cuda.set_device(local)
+            with torch.cuda.stream(probe_stream):
+                while not clock["stop"]:
+                    try:
+                        clock["samples"].append(probe_eng.shader_clock_ghz(20000))
+                    except Exception:
+                        return
+        probe = threading.Thread(target=probe_loop)
     sharding.barrier(info, eng.device)
+    if probe:
+        probe.start()
     t0 = time.perf_counter()
     run_steps(steps, timed=True)
     sharding.barrier(info, eng.device)
     dt = time.perf_counter() - t0
+    if probe:
+        clock["stop"] = True
+        probe.join()
+        probe_eng.close()
     res = acc["res"]
 
     # solution quality on this shard (not part of the timed region)
@@ -344,12 +396,32 @@ def measure(args, info, sharding, cfg_id, steps, warmup, D, batch=0, storage="f3
 
     dom_ms, dom_bytes, dom_n, n_prof = acc["dom_ms"], acc["dom_bytes"], acc["dom_n"], acc["n_prof"]
     ms_per_step = dt / steps * 1e3
+    # iterations/s per pyramid level -- executed pair-iterations of a level over the time its iteration
+    # kernel launches took (HIP events, event-bracketed steps), next to the roofline fraction of those launches.  The
+    # peak-rate column is what 8 TB/s would allow at that level's size (954 k/s at 1024^2, 3.81 M/s at 512^2, ...).
+    per_level = []
+    for s in range(ns):
+        w, h = acc["lvl_wh"][s]
+        ms, by, un = acc["lvl_ms"][s] + acc["lvl_first_ms"][s], acc["lvl_bytes"][s], acc["lvl_units"][s]
+        per_level.append({
+            "level": s, "width": w, "height": h,
+            "mean_iterations_per_pair": acc["per_scale"][s] / float(B * steps),
+            "pair_iterations_per_s": (un / (ms * 1e-3)) if ms > 0 else None,
+            "peak_pair_iterations_per_s": HBM_PEAK_GBS * 1e9 / (2.0 * w * h * C * 4) if w and h else None,
+            "frac": (by / (acc["lvl_ms"][s] * 1e-3) / 1e9 / HBM_PEAK_GBS) if acc["lvl_ms"][s] > 0 else None,
+            "iteration_kernel_ms_per_step": ms / max(n_prof, 1),
+            "launches_per_step": (acc["lvl_n"][s] + acc["lvl_first_n"][s]) / max(n_prof, 1)})
+    cs = sorted(clock["samples"])
+    shader_clock = ({"mean_ghz": sum(cs) / len(cs), "min_ghz": cs[0], "max_ghz": cs[-1], "samples": len(cs),
+                     "method": "one wave on a second stream during the timed region: s_memtime / s_memrealtime, 20 ms each"}
+                    if cs else None)
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     ratio, src = measured_traffic(cfg)
     out = dict(
         cfg=cfg, dt=dt, units_all=units_all, pairs_all=pairs_all, ms_per_step=ms_per_step,
         step_latency_ms=acc["latency"] / max(steps, 1) * 1e3, gen_seconds=t_gen,
         mean_iters_per_scale=[acc["per_scale"][s] / float(B * steps) for s in range(ns)],
+        per_level=per_level, shader_clock=shader_clock,
         roofline={
             "bound": "hbm",
             "kernel": f"ica_iterate_kernel{kernel_key(cfg)} ({TNAME[cfg['transform']]}, "
@@ -457,6 +529,7 @@ def main():
                                "storage": stor, "value": s["units_all"] / s["dt"], "unit": "pair-iterations/s",
                                "steps": steps, "warmup": 1, "ms_per_step": s["ms_per_step"],
                                "image_pairs_per_s": s["pairs_all"] / s["dt"],
+                               "per_level": s["per_level"], "shader_clock": s["shader_clock"],
                                "roofline": {k: s["roofline"][k] for k in ("kernel", "achieved", "frac", "avg_launch_ms",
                                                                           "launches", "traffic", "algorithmic_bytes_per_launch",
                                                                           "scale0", "scale0_frac_1B_convention")},
@@ -490,6 +563,9 @@ def main():
             "image_pairs_per_s": m["pairs_all"] / m["dt"],
             "pair_iterations_per_step": m["units_all"] / args.steps,
             "mean_iters_per_scale": m["mean_iters_per_scale"],
+            "per_level": m["per_level"],
+            "shader_clock": m["shader_clock"],
+            "library_fingerprint": library_fingerprint(),
             "roofline": m["roofline"],
             "quality": m["quality"],
         }

@@ -34,7 +34,10 @@ for s, args in cmds.items():
         v["command"] = d["command"]
         kernels[key] = v
 old = json.load(open(os.path.join(pr, "r02_traffic.json")))
-json.dump({"what": old["what"], "kernels": kernels}, open(os.path.join(pr, f"{t}_traffic.json"), "w"), indent=1)
+json.dump({"what": old["what"] + "  library_fingerprint = the source fingerprint (build stamp) of the library the counters were "
+           "collected on: bench.py reports roofline.traffic only when it is the library it has loaded.",
+           "library_fingerprint": rd(f"{t}_fingerprint.txt").strip(), "kernels": kernels},
+          open(os.path.join(pr, f"{t}_traffic.json"), "w"), indent=1)
 line = rd(f"{t}_bench_line.json").strip().splitlines()[-1]
 json.loads(line)
 open(os.path.join(pr, f"{t}_bench_line.json"), "w").write(line + "\n")

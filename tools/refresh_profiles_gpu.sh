@@ -7,6 +7,8 @@
 t=$1
 R=$GRAFT_REPO_ROOT
 set -e
+# the library these measurements are taken on (bench.py reports roofline.traffic only for this very build)
+(cd $R && python3 -c "from inverse_compositional_algorithm_amd import build; print(build.read_stamp()[0])") > $R/gpurun_out/${t}_fingerprint.txt
 for cfg in 2 3 4 5; do
   timeout -k 10 400 $R/tools/prof_bench.sh ${t}_bs_cfg$cfg --config $cfg > /dev/null; echo "bench summary cfg $cfg done"
 done
