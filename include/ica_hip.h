@@ -20,6 +20,15 @@
  *   - transform parameters are float64, 8 per pair, zero padded: p[b*8 + k], k < nparams.
  *   - "_dev" functions take DEVICE pointers and enqueue on the context's stream without
  *     synchronising (except where noted); the others take HOST pointers, copy, run and synchronise.
+ *     ica_solve_batch_dev is the exception that matters: it never calls a device-wide synchronise, but it is a
+ *     HOST-BLOCKING call.  The number of pairs still iterating sizes every next launch, and the host reads it from a
+ *     pinned board the kernels post to, staying exactly one iteration ahead of the GPU: the calling thread polls
+ *     (yielding the core; sleeping between polls after 4 ms) for the whole solve and returns about one iteration
+ *     before the GPU finishes -- the outputs are still only valid after a sync.  Budget one host thread per ctx for
+ *     the duration of a solve (8 on an 8-GPU node); ICA_BOARD_TIMEOUT_MS (default 10000) bounds each wait.
+ *   - layout: every image / output argument is dense [batch][channels][height][width] with no padding (row stride =
+ *     width elements, plane stride = height * width): ica_problem carries no stride fields.  Strided or interleaved
+ *     (H, W, C) data is repacked by the caller (the Python layer does).
  *   - every function returns ICA_OK (0) or a negative ica_status.
  *   - one ica_ctx per GPU; a ctx is not thread-safe, different ctxs are independent.
  */
