@@ -228,8 +228,12 @@ def measure(args, info, sharding, cfg_id, steps, warmup, D, batch=0, storage="f3
     if batch:
         cfg["batch"] = batch
     torch.cuda.set_device(local)
-    eng = IcaEngine(local)
     B, H, W, C = cfg["batch"], cfg["H"], cfg["W"], cfg["C"]
+    # the shard must fit before anything is allocated (configs[4]: ~68 GB per GPU of 288)
+    free_b, total_b = torch.cuda.mem_get_info(local)
+    need_b = sharding.shard_device_bytes(B, H, W, C, cfg["nscales"], 0.5, 1 if storage == "u8" else 4)
+    sharding.check_memory_budget(need_b, free_b, total_b, f"rank {info.rank}: the shard of {cfg['name']}")
+    eng = IcaEngine(local)
     # each rank owns its own shard of pairs, generated on its own device (no host staging, no exchange)
     t_gen = time.perf_counter()
     I1, I2, p_gt = eng.make_batch(sharding.shard_seed(cfg_id, info.rank), B, H, W, C, cfg["transform"],
@@ -488,6 +492,8 @@ def main():
         print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing to report a "
               f"number for a job of another size", file=sys.stderr)
         sys.exit(2)
+    if world > 1:
+        sharding.pin_rank(info)  # one polling host thread per rank: every rank keeps its own cores
     if world > 1 and not stub:
         torch.cuda.set_device(local)
     sharding.init("gloo" if stub else "nccl", info)  # backend "nccl" is RCCL on ROCm; barrier + 3 scalars only

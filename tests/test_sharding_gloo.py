@@ -86,3 +86,37 @@ def test_bench_without_a_gpu_fails_loudly():
         pytest.skip("GPU present")
     rc, out, err = _bench(["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-per-config"], {})
     assert rc != 0 and out is None
+
+
+def test_bench_gpus_8_rehearsal_on_cpu():
+    """The 8-rank launch path the driver uses at round end, rehearsed with gloo and the stub engine: eight ranks are
+    started, count themselves, pin themselves to their own cores and aggregate MAX time / SUM units."""
+    rc, out, err = _bench(["--gpus", "8", "--steps", "2", "--warmup", "0"], {"BENCH_STUB": "1"}, timeout=600)
+    assert rc == 0, err[-2000:]
+    assert out["n_gpus"] == 8 and out["stub"] is True
+    assert out["units"] == 100.0 * 2 * sum(range(1, 9)) and out["pairs"] == 8 * 8.0 * 2
+
+
+def test_shard_memory_budget():
+    from inverse_compositional_algorithm_amd import sharding
+    # BASELINE configs[4]: 1024 pairs of 1920 x 1080 x 3 per GPU, 5 scales -- ~51 GB of level-0 images + ~17 GB of levels
+    need = sharding.shard_device_bytes(1024, 1080, 1920, 3, 5, 0.5, 4)
+    assert 66e9 < need < 72e9
+    assert sharding.shard_device_bytes(1024, 1080, 1920, 3, 5, 0.5, 1) < 0.45 * need   # uint8 level-0 storage
+    gib = 2 ** 30
+    sharding.check_memory_budget(need, 280 * gib, 288 * gib, "the shard")          # fits an MI355X
+    with pytest.raises(MemoryError, match="needs .* GiB of device memory.*fewer pairs"):
+        sharding.check_memory_budget(need, 60 * gib, 288 * gib, "the shard")        # someone else holds the card
+    with pytest.raises(MemoryError):
+        sharding.check_memory_budget(5 * need, 280 * gib, 288 * gib, "a 5120-pair shard")
+
+
+def test_ranks_keep_disjoint_cores():
+    from inverse_compositional_algorithm_amd import sharding
+    cores = list(range(3, 19))                      # 16 allowed cores
+    got = [sharding.cores_for_rank(r, 8, cores) for r in range(8)]
+    assert all(len(g) == 2 for g in got)
+    assert sorted(c for g in got for c in g) == cores          # disjoint and complete
+    assert sharding.cores_for_rank(0, 1, cores) == cores        # a single rank keeps everything
+    few = [sharding.cores_for_rank(r, 8, [0, 1, 2]) for r in range(8)]
+    assert all(len(g) == 1 for g in few) and {g[0] for g in few} == {0, 1, 2}
