@@ -785,9 +785,20 @@ __global__ __launch_bounds__(kIterBlock, (C == 1 ? (U8 ? ICA_ITER_WAVES_U8 : ICA
 #pragma unroll
       for (int c = 0; c < C; ++c) { cm[c] = i1p[c * P1 * R1]; cd[c] = i1p[c * P1 * R1 + P1]; }
       [[maybe_unused]] const unsigned i1a = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)i1p;
+#ifdef ICA_PROBE_I1LOAD   // timing probe: what do per-lane global loads of the I1 row (left, centre, right) cost in the band?
+      typedef int probe_v3 __attribute__((ext_vector_type(3)));
+      probe_v3 pre[RW + 2];
+      const int probe_off = ((yb0 - 1) * W + (x - 1)) * 4;
+      pre[0] = __builtin_amdgcn_raw_buffer_load_b96(rs1, probe_off, 0, 0);
+      pre[1] = __builtin_amdgcn_raw_buffer_load_b96(rs1, probe_off + W * 4, 0, 0);
+#endif
 #pragma unroll
       for (int i = 0; i < RW; ++i) {
         const float yf = i == 0 ? yf0 : yf0 + (float)i;  // exact (small integers); a VGPR because yf0 is one
+#ifdef ICA_PROBE_I1LOAD
+        pre[i + 2] = __builtin_amdgcn_raw_buffer_load_b96(rs1, probe_off + (i + 2) * W * 4, 0, 0);
+        asm volatile("" ::"v"(pre[i].x), "v"(pre[i].y), "v"(pre[i].z));
+#endif
         [[maybe_unused]] bool live = true;
         if constexpr (MASKED) {
           const int y = yb0 + i;  // wave-uniform
