@@ -87,8 +87,11 @@ def test_hip_reproduces_reference_runs(run):
         for _ in range(s):
             w, h = oc.zoom_size(w, h, run["nu"])
         for k, it in enumerate(sc["iterations"]):
-            assert _corner_disp(tr[s, k, 1:1 + n], np.array(it["p"]), t, h, w) <= 5e-3
-            np.testing.assert_allclose(tr[s, k, 0], it["dp_norm"], rtol=5e-2, atol=2e-5)
+            # the trajectory under the end point's tolerance.  Measured over all 36 committed runs
+            # (profiles/r03_golden_parity.txt): every iterate within 6.3e-6 px, every |dp| within 1.5e-6 absolute and
+            # 1.3e-3 of max(|dp|, TOL); the bounds below leave a factor of ~10.
+            assert _corner_disp(tr[s, k, 1:1 + n], np.array(it["p"]), t, h, w) <= 1e-4
+            np.testing.assert_allclose(tr[s, k, 0], it["dp_norm"], rtol=1e-3, atol=2e-5)
     Iw = res.Iw[0, 0].cpu().numpy()
     assert int(np.isnan(Iw).sum()) == run["iw_nan_count"]
     np.testing.assert_allclose(float(np.nansum(Iw.astype(np.float64))), run["iw_checksum"], rtol=1e-5)
@@ -135,10 +138,12 @@ def test_hip_reproduces_reference_at_baseline_config_sizes(run):
     """BASELINE.json configs[0..4] at full image size (plus configs[4] at quarter size): recovered parameters
     within 1e-4 relative / 1e-3 px of the reference's and the same iteration count at every scale --
     also for the runs in which the reference exhausts its 30 iterations at some scale.
-    (Measured: <= 6e-8 relative, <= 3e-6 px; profiles/r01_golden_parity.txt.)"""
+    (Measured, 24 runs: <= 2e-7 relative, <= 1.8e-6 px, every iterate of every scale within 6.3e-6 px;
+    profiles/r03_golden_parity.txt.)  The whole trajectory is held to 1e-4 px and every |dp| to 1e-3 relative."""
     t, n = run["transform"], oc.nparams(run["transform"])
-    res = _hip_solve(run)
+    res = _hip_solve(run, want_trace=True)
     p = res.p[0, :n].cpu().numpy()
+    tr = res.trace[0].cpu().numpy()
     nit = [int(v) for v in res.niter[0].cpu().numpy()]
     want_nit = {sc["scale"]: len(sc["iterations"]) for sc in run["scales"]}
     want_p = np.array(run["p"])
@@ -146,6 +151,13 @@ def test_hip_reproduces_reference_at_baseline_config_sizes(run):
     assert nit == [want_nit[s] for s in range(run["nscales"])]
     assert rel <= 1e-4, f"relative parameter error {rel:.2e}"
     assert _corner_disp(p, want_p, t, run["H"], run["W"]) <= 1e-3
+    for sc in run["scales"]:
+        s, h, w = sc["scale"], run["H"], run["W"]
+        for _ in range(s):
+            w, h = oc.zoom_size(w, h, run["nu"])
+        for k, it in enumerate(sc["iterations"]):
+            assert _corner_disp(tr[s, k, 1:1 + n], np.array(it["p"]), t, h, w) <= 1e-4
+            np.testing.assert_allclose(tr[s, k, 0], it["dp_norm"], rtol=1e-3, atol=2e-5)
 
 
 @pytest.mark.parametrize("run", [r for r in CFG_RUNS if r["name"] in ("configs0_pair0", "configs0_pair1", "configs1_pair0")],

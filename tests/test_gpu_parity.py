@@ -644,7 +644,7 @@ def test_a_pair_too_large_for_32_bit_offsets_is_refused(eng):
     from inverse_compositional_algorithm_amd._lib import check
     with pytest.raises(IcaError) as e:  # the descriptor is refused before anything is allocated or launched
         check(eng.lib.ica_prepare(eng.ctx, ctypes.byref(prob)), eng.ctx)
-    assert e.value.status == -1
+    assert e.value.status == -6  # ICA_EINVAL_ARG
 
 
 def test_operator_wrappers_check_shapes(eng):
