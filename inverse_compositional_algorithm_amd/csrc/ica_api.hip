@@ -151,18 +151,26 @@ int validate(const ica_problem* pr) {
 #ifndef ICA_MIN_BLOCKS   // a launch is cut into shorter tiles until it has this many workgroups (1536 are resident)
 #define ICA_MIN_BLOCKS 2048
 #endif
-void set_tiling(LevelGeom& g, int pairs, int max_tile_h) {
+// `chunk` = rows per chunk of the kernel that will run the level (iter_chunk_rows): tile heights are whole chunks, so
+// that only an image's last tile ends in a partial chunk (a partial chunk takes the careful band).
+void set_tiling(LevelGeom& g, int pairs, int max_tile_h, int chunk) {
   g.tiles_x = (g.W + kTileW - 1) / kTileW;
-  // (at most 32 chunks of 16 or 32 rows per tile: the chunk plans of a tile live in one register)
-  int th = std::max(ICA_MIN_TH, std::min(512, max_tile_h));
+  // (at most 32 chunks per tile: the chunk plans of a tile live in one register)
+  auto whole = [&](int th) { return th >= chunk ? (th / chunk) * chunk : th; };
+  int th = whole(std::max(ICA_MIN_TH, std::min(std::min(512, 32 * chunk), max_tile_h)));
   while (th > ICA_MIN_TH) {
     const long blocks = (long)pairs * g.tiles_x * ((g.H + th - 1) / th);
     if (blocks >= ICA_MIN_BLOCKS && th <= std::max(ICA_MIN_TH, g.H)) break;
-    th >>= 1;
+    th = std::max(ICA_MIN_TH, whole(th >> 1));
   }
   g.tile_h = th;
   g.tiles_y = (g.H + th - 1) / th;
   g.tiles = g.tiles_x * g.tiles_y;
+}
+
+// rows per chunk of the iteration kernel of level `s` of a problem (uint8 storage applies to level 0 only)
+int level_chunk(const ica_problem* pr, int s) {
+  return iter_chunk_rows(pr->channels, pr->storage == ICA_STORAGE_U8 && s == 0);
 }
 
 void level_sizes(const ica_ctx* ctx, const ica_problem* pr, LevelGeom* g) {
@@ -172,7 +180,7 @@ void level_sizes(const ica_ctx* ctx, const ica_problem* pr, LevelGeom* g) {
     g[s].W = std::max(1, round_half_even(g[s - 1].W * pr->nu));
     g[s].H = std::max(1, round_half_even(g[s - 1].H * pr->nu));
   }
-  for (int s = 0; s < pr->nscales; ++s) set_tiling(g[s], pr->batch, ctx->max_tile_h);
+  for (int s = 0; s < pr->nscales; ++s) set_tiling(g[s], pr->batch, ctx->max_tile_h, level_chunk(pr, s));
 }
 
 int get_op(ica_ctx* ctx, int n_in, int n_out, DeviceBandOp** out) {
@@ -502,7 +510,7 @@ int ensure_state(ica_ctx* ctx, const ica_problem* pr, const LevelGeom* g) {
   for (int s = 0; s < pr->nscales; ++s)
     for (int nb = 1; nb <= pr->batch; nb = (nb < pr->batch && nb * 2 > pr->batch) ? pr->batch : nb * 2) {
       LevelGeom t = g[s];
-      set_tiling(t, nb, ctx->max_tile_h);
+      set_tiling(t, nb, ctx->max_tile_h, level_chunk(pr, s));
       // the tiling is chosen for the polled count, which can only over-estimate the pairs of later launches
       max_slots_tiles = std::max(max_slots_tiles, (size_t)std::min<long>(pr->batch, 2L * nb) * t.tiles);
       if (nb == pr->batch) break;
@@ -798,7 +806,7 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const void* I1v, co
         if (nb == 0) break;
       }
       la.host_slot = ctx->board_dev + (size_t)s * max_iter + it;
-      set_tiling(lg, nb, ctx->max_tile_h);  // accumulate and solve of one iteration always agree on the tiling
+      set_tiling(lg, nb, ctx->max_tile_h, level_chunk(pr, s));  // accumulate and solve of one iteration always agree on the tiling
       la.tiles_x = lg.tiles_x; la.tiles_y = lg.tiles_y; la.tile_h = lg.tile_h;
       la.act_list = lists + (size_t)cur * list_stride;
       la.act_count = counts + (size_t)cur * cnt_stride;

@@ -15,6 +15,24 @@
 
 namespace ica {
 
+// ---- chunk heights of the fused iteration kernel (ica_iterate.hpp), needed by the host to pick tile heights -------
+#ifndef ICA_LOADER   // n > 0: kernels of one-channel float32 levels run with n LOADER waves (ica_iterate.hpp, IterCfg); measured slower
+#define ICA_LOADER 0
+#endif
+#ifndef ICA_CH_LOADER   // image rows per chunk of those kernels
+#define ICA_CH_LOADER 24
+#endif
+#ifndef ICA_CH     // image rows per chunk, one channel, no loader wave
+#define ICA_CH 32
+#endif
+#ifndef ICA_CH3    // image rows per chunk, three channels (a 32-row tile of three channels does not fit the LDS)
+#define ICA_CH3 16
+#endif
+// rows per chunk of the kernel that runs a level of `channels` channels stored as uint8 (`u8`) or float32
+constexpr int iter_chunk_rows(int channels, bool u8) {
+  return (ICA_LOADER != 0 && channels == 1 && !u8) ? ICA_CH_LOADER : channels == 1 ? ICA_CH : ICA_CH3;
+}
+
 constexpr int kBlock = 256;   // 4 waves
 constexpr int kTileW = 64;    // one lane per column of a tile
 constexpr int kWaves = kBlock / 64;

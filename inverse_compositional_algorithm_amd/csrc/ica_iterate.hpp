@@ -64,14 +64,26 @@
 
 #include "ica_common.hpp"
 
-#ifndef ICA_WG_WAVES   // waves per workgroup of the iteration kernel (each walks ch / waves rows of a chunk)
-#define ICA_WG_WAVES 4
-#endif
-
 namespace ica {
 
-constexpr int kIterWaves = ICA_WG_WAVES;
-constexpr int kIterBlock = 64 * kIterWaves;
+constexpr int kComputeWaves = 4;   // waves of a workgroup that walk rows (ch / 4 each)
+
+// Shape of a workgroup per instantiation.
+// ICA_LOADER = n > 0 (an experiment, off by default): n extra LOADER waves issue every LDS-DMA copy of the workgroup and
+// compute nothing, the four computing waves never issue or wait for a copy; chunk k + 1 is copied into a second tile
+// while chunk k is computed (two 18 KB tiles of 24-row chunks, 4 workgroups per CU), one barrier per chunk.  The idea:
+// in the round-2 kernel a wave spends 8.5 % of its time issuing its share of the copies (~180 cycles per 1 KB
+// instruction), 10.8 % waiting for them to land and 2.4 % at the barrier in front (profiles/r03_stamps_*), time in which
+// it does not compete for the vector ALU -- which the kernel without copies keeps ~85 % busy and the kernel with copies
+// 68 %.  Measured (profiles/r03_ablation.txt): 3395 us with one loader wave and 3887 us with two against 2660 us for the
+// robust homography kernel, 3144 against 2238 for L2 homography: the copies of a chunk, issued by one or two waves
+// one after the other, take longer than the four computing waves need for the chunk.
+template <int C, bool U8> struct IterCfg {
+  static constexpr bool loader = (ICA_LOADER != 0) && C == 1 && !U8;
+  static constexpr int copy_waves = loader ? ICA_LOADER : kComputeWaves;   // ICA_LOADER = number of loader waves
+  static constexpr int waves = kComputeWaves + (loader ? copy_waves : 0);
+  static constexpr int block = 64 * waves;
+};
 
 #ifdef ICA_STAMP
 // Diagnostic build (tools/mkvariant.sh stamp -DICA_STAMP): shader cycles a wave spends in each phase of a chunk, summed
@@ -125,7 +137,7 @@ template <int TT> struct MomLayout {
   static constexpr int maxpow = 2 * mby > 2 * mbx ? 2 * mby : 2 * mbx;  // highest y power any moment needs
 };
 
-template <int C> struct TileCfg {
+template <int C, bool LOADER = false> struct TileCfg {
   // Image rows per chunk: 4 waves x ch/4 rows.  One channel: 32 rows in ONE 22.9 KB tile (6 workgroups per CU), copy and
   // arithmetic of a workgroup alternate and the other five overlap them.  Measured against 16-row chunks in two tiles
   // (chunk k+1 copied under chunk k's arithmetic, 26.4 KB): 3-7 % faster on every one-channel kernel -- half the
@@ -134,11 +146,12 @@ template <int C> struct TileCfg {
   // uses the same chunk (bit-identical results need the same rows in the same waves); with its staging area it holds
   // 28.6 KB, 5 workgroups per CU, and is still 4 % faster than with 16-row chunks.
   // Three channels: 16 rows, one 39.5 KB tile, 4 workgroups per CU.
-  static constexpr int ch = (C == 1) ? ICA_CH : ICA_CH3;
-  static constexpr int rw = ch / kIterWaves;
+  static constexpr int ch = LOADER ? ICA_CH_LOADER : (C == 1) ? ICA_CH : ICA_CH3;
+  static constexpr int rw = ch / kComputeWaves;
+  static_assert(ch % kComputeWaves == 0, "a chunk is split evenly among the computing waves");
   static constexpr int p2 = 80, r2 = ch + 9;           // I2 footprint buffer: pitch (floats) x rows
   static constexpr int p1 = 72, r1 = ch + 2;           // I1 buffer: columns x_t0-4 .. x_t0+67, rows yc0-1 .. yc0+ch
-  static constexpr int nbuf = (C == 1) ? ICA_NBUF : 1;
+  static constexpr int nbuf = LOADER ? 2 : (C == 1) ? ICA_NBUF : 1;
   static constexpr int buf_floats = C * (p2 * r2 + p1 * r1);
 };
 
@@ -275,7 +288,10 @@ __device__ __forceinline__ float rho_prime_t(float t2, float lam2) {
 // workgroup: barrier, expand chunk k, barrier, start the copy of chunk k+1, compute chunk k.
 template <int TT, int MODE, int C, int RT, bool U8>
 // (second launch bound = waves per SIMD the register allocator must leave room for: what the LDS footprint allows)
-__global__ __launch_bounds__(kIterBlock, (C == 1 ? (U8 ? ICA_ITER_WAVES_U8 : ICA_ITER_WAVES) : U8 ? 3 : 4)) void ica_iterate_kernel(LevelArgs a) {
+__global__ __launch_bounds__((IterCfg<C, U8>::block), (IterCfg<C, U8>::loader ? (IterCfg<C, U8>::waves * 4 + 3) / 4 : C == 1 ? (U8 ? ICA_ITER_WAVES_U8 : ICA_ITER_WAVES) : U8 ? 3 : 4)) void ica_iterate_kernel(LevelArgs a) {
+  using WG = IterCfg<C, U8>;
+  constexpr bool kLoader = WG::loader;
+  constexpr int kIterWaves = WG::waves, kIterBlock = WG::block, kCopyWaves = WG::copy_waves;
   using TIn = std::conditional_t<U8, unsigned char, float>;
   constexpr int ES = (int)sizeof(TIn);    // bytes per image element in HBM
   constexpr int N = NP<TT>::n;
@@ -285,7 +301,7 @@ __global__ __launch_bounds__(kIterBlock, (C == 1 ? (U8 ? ICA_ITER_WAVES_U8 : ICA
   constexpr bool kProj = (TT == ICA_HOMOGRAPHY);
   constexpr bool kRobust = (MODE == kModeRobust);
   using ML = MomLayout<TT>;
-  using TC = TileCfg<C>;
+  using TC = TileCfg<C, kLoader>;
   constexpr int CH = TC::ch, RW = TC::rw, P2 = TC::p2, R2 = TC::r2, P1 = TC::p1, R1 = TC::r1;
   constexpr int NBUF = U8 ? 1 : TC::nbuf;                 // float tiles
   constexpr int kStageFloats = U8 ? TC::buf_floats / 4 : 0;  // uint8 staging area, in floats (4 pixels each)
@@ -503,7 +519,8 @@ __global__ __launch_bounds__(kIterBlock, (C == 1 ? (U8 ? ICA_ITER_WAVES_U8 : ICA
   // (Fetching only the rows a chunk does NOT share with its predecessor and moving the shared ones LDS -> LDS -- 9 of
   //  the 25 I2 rows, 2 of the 18 I1 rows -- was built and measured: a quarter fewer L1 requests, but 9 % MORE time;
   //  the move and its dependency sit in front of the copies.  profiles/r02_ablation.txt)
-  auto issue = [&](int k, int buf) {
+  const bool copies = !kLoader || wave >= kComputeWaves;   // (with loader waves: they alone copy)
+  auto issue_impl = [&](int k, int buf) {
 #if defined(ICA_ABLATE) && (ICA_ABLATE & 2)   // (ICA_ABLATE is a set of bits: 1 copies only, 2 no copies, 4 lane-linear taps, 8 no barriers)
     return;  // timing-only build: no LDS-DMA
 #endif
@@ -518,8 +535,8 @@ __global__ __launch_bounds__(kIterBlock, (C == 1 ? (U8 ? ICA_ITER_WAVES_U8 : ICA
       // may wrap below 0 (row -1): then out of range.  A skipped chunk gets an out-of-range base.
       const unsigned base1 = skip ? 0x40000000u : (unsigned)(((yc0 - 1) * W + x_t0) * ES);
 #pragma unroll
-      for (int qq = 0; qq < (NQ1 + kIterWaves - 1) / kIterWaves; ++qq) {
-        const int q = wave + qq * kIterWaves;      // this wave's row group (wave-uniform)
+      for (int qq = 0; qq < (NQ1 + kCopyWaves - 1) / kCopyWaves; ++qq) {
+        const int q = (kLoader ? wave - kComputeWaves : wave) + qq * kCopyWaves;      // this wave's row group (wave-uniform)
         // Lanes past the tile's last row must not take part at all: an out-of-range lane still writes its (zero) result
         // to LDS, which would land in the neighbouring tile.
         const int rows = min(RP1, R1 - RP1 * q);
@@ -543,8 +560,8 @@ __global__ __launch_bounds__(kIterBlock, (C == 1 ? (U8 ? ICA_ITER_WAVES_U8 : ICA
             (void*)I2, 0, bh ? (int)(((size_t)(C - 1) * plane + (size_t)(y_lo + bh) * W) * ES) : 0, 0x00020000);
         const unsigned base2 = (unsigned)((y_lo * W + x_lo) * ES);
 #pragma unroll
-        for (int qq = 0; qq < (NQ2 + kIterWaves - 1) / kIterWaves; ++qq) {
-          const int q = wave + qq * kIterWaves;
+        for (int qq = 0; qq < (NQ2 + kCopyWaves - 1) / kCopyWaves; ++qq) {
+          const int q = (kLoader ? wave - kComputeWaves : wave) + qq * kCopyWaves;
           const int rows = min(RP2, R2 - RP2 * q);
           if (q < NQ2 && lane < V2 * rows) {
             TIn* dst = b2 + RP2 * q * P2;
@@ -559,7 +576,7 @@ __global__ __launch_bounds__(kIterBlock, (C == 1 ? (U8 ? ICA_ITER_WAVES_U8 : ICA
       }
     } else if constexpr (!U8) {
       if (px & (1 << 29)) return;
-      for (int r = wave; r < R1; r += kIterWaves) {
+      for (int r = (kLoader ? wave - kComputeWaves : wave); r < R1; r += kCopyWaves) {
         const int yy = yc0 - 1 + r;
         if (yy < 0 || yy >= H) continue;
 #pragma unroll
@@ -572,7 +589,7 @@ __global__ __launch_bounds__(kIterBlock, (C == 1 ? (U8 ? ICA_ITER_WAVES_U8 : ICA
       }
       if (kB && (px & (1 << 30))) {
         const int x_lo = px & 0xFFFFF;
-        for (int r = wave; r < R2; r += kIterWaves) {
+        for (int r = (kLoader ? wave - kComputeWaves : wave); r < R2; r += kCopyWaves) {
           const int yy = y_lo + r;
           if (yy >= H) break;
 #pragma unroll
@@ -587,6 +604,9 @@ __global__ __launch_bounds__(kIterBlock, (C == 1 ? (U8 ? ICA_ITER_WAVES_U8 : ICA
     }
   };
 
+  auto issue = [&](int k, int buf) {
+    if (copies) issue_impl(k, buf);
+  };
   if (!w4) {  // the dword copy path skips out-of-image lanes instead of zero-filling them: start from finite LDS
     for (int i = threadIdx.x; i < kLdsFloats; i += kIterBlock) lds[i] = 0.f;
     __syncthreads();
@@ -1042,7 +1062,7 @@ __global__ __launch_bounds__(kIterBlock, (C == 1 ? (U8 ? ICA_ITER_WAVES_U8 : ICA
 #if defined(ICA_ABLATE) && (ICA_ABLATE & 1)
     if (a.delta < 0)  // timing-only build: staging and barriers only
 #endif
-    {
+    if (!kLoader || wave < kComputeWaves) {
       if constexpr (CLS == 0) band_fast(std::false_type{});
       else if constexpr (CLS == 1) band_fast(std::true_type{});
       else if constexpr (CLS == 3) {  // (one loop, the class looked up per chunk)

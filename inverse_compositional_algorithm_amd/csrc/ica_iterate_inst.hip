@@ -13,11 +13,11 @@ namespace {
 template <int TT, int MODE, int RT>
 void launch_c(int channels, unsigned blocks, hipStream_t st, const LevelArgs& a) {
   if (a.u8) {  // this level's images are uint8 in HBM (level 0 of an ICA_STORAGE_U8 problem)
-    if (channels == 1) hipLaunchKernelGGL((ica_iterate_kernel<TT, MODE, 1, RT, true>), dim3(blocks), dim3(kIterBlock), 0, st, a);
-    else hipLaunchKernelGGL((ica_iterate_kernel<TT, MODE, 3, RT, true>), dim3(blocks), dim3(kIterBlock), 0, st, a);
+    if (channels == 1) hipLaunchKernelGGL((ica_iterate_kernel<TT, MODE, 1, RT, true>), dim3(blocks), dim3(IterCfg<1, true>::block), 0, st, a);
+    else hipLaunchKernelGGL((ica_iterate_kernel<TT, MODE, 3, RT, true>), dim3(blocks), dim3(IterCfg<3, true>::block), 0, st, a);
   } else {
-    if (channels == 1) hipLaunchKernelGGL((ica_iterate_kernel<TT, MODE, 1, RT, false>), dim3(blocks), dim3(kIterBlock), 0, st, a);
-    else hipLaunchKernelGGL((ica_iterate_kernel<TT, MODE, 3, RT, false>), dim3(blocks), dim3(kIterBlock), 0, st, a);
+    if (channels == 1) hipLaunchKernelGGL((ica_iterate_kernel<TT, MODE, 1, RT, false>), dim3(blocks), dim3(IterCfg<1, false>::block), 0, st, a);
+    else hipLaunchKernelGGL((ica_iterate_kernel<TT, MODE, 3, RT, false>), dim3(blocks), dim3(IterCfg<3, false>::block), 0, st, a);
   }
 }
 
