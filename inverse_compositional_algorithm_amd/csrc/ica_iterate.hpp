@@ -66,7 +66,11 @@
 
 namespace ica {
 
-constexpr int kComputeWaves = 4;   // waves of a workgroup that walk rows (ch / 4 each)
+#ifndef ICA_CWAVES3   // computing waves per workgroup, three channels (8 with ICA_CH3=32: one 68.7 KB tile, 2 workgroups per CU)
+#define ICA_CWAVES3 4
+#endif
+// waves of a workgroup that walk rows (ch / compute_waves each)
+constexpr int compute_waves(int channels) { return channels == 3 ? ICA_CWAVES3 : 4; }
 
 // Shape of a workgroup per instantiation.
 // ICA_LOADER = n > 0 (an experiment, off by default): n extra LOADER waves issue every LDS-DMA copy of the workgroup and
@@ -80,8 +84,9 @@ constexpr int kComputeWaves = 4;   // waves of a workgroup that walk rows (ch / 
 // one after the other, take longer than the four computing waves need for the chunk.
 template <int C, bool U8> struct IterCfg {
   static constexpr bool loader = (ICA_LOADER != 0) && C == 1 && !U8;
-  static constexpr int copy_waves = loader ? ICA_LOADER : kComputeWaves;   // ICA_LOADER = number of loader waves
-  static constexpr int waves = kComputeWaves + (loader ? copy_waves : 0);
+  static constexpr int cw = compute_waves(C);
+  static constexpr int copy_waves = loader ? ICA_LOADER : cw;   // ICA_LOADER = number of loader waves
+  static constexpr int waves = cw + (loader ? copy_waves : 0);
   static constexpr int block = 64 * waves;
 };
 
@@ -147,8 +152,8 @@ template <int C, bool LOADER = false> struct TileCfg {
   // 28.6 KB, 5 workgroups per CU, and is still 4 % faster than with 16-row chunks.
   // Three channels: 16 rows, one 39.5 KB tile, 4 workgroups per CU.
   static constexpr int ch = LOADER ? ICA_CH_LOADER : (C == 1) ? ICA_CH : ICA_CH3;
-  static constexpr int rw = ch / kComputeWaves;
-  static_assert(ch % kComputeWaves == 0, "a chunk is split evenly among the computing waves");
+  static constexpr int rw = ch / compute_waves(C);
+  static_assert(ch % compute_waves(C) == 0, "a chunk is split evenly among the computing waves");
   static constexpr int p2 = 80, r2 = ch + 9;           // I2 footprint buffer: pitch (floats) x rows
   static constexpr int p1 = 72, r1 = ch + 2;           // I1 buffer: columns x_t0-4 .. x_t0+67, rows yc0-1 .. yc0+ch
   static constexpr int nbuf = LOADER ? 2 : (C == 1) ? ICA_NBUF : 1;
@@ -291,7 +296,7 @@ template <int TT, int MODE, int C, int RT, bool U8>
 __global__ __launch_bounds__((IterCfg<C, U8>::block), (IterCfg<C, U8>::loader ? (IterCfg<C, U8>::waves * 4 + 3) / 4 : C == 1 ? (U8 ? ICA_ITER_WAVES_U8 : ICA_ITER_WAVES) : U8 ? 3 : 4)) void ica_iterate_kernel(LevelArgs a) {
   using WG = IterCfg<C, U8>;
   constexpr bool kLoader = WG::loader;
-  constexpr int kIterWaves = WG::waves, kIterBlock = WG::block, kCopyWaves = WG::copy_waves;
+  constexpr int kIterWaves = WG::waves, kIterBlock = WG::block, kCopyWaves = WG::copy_waves, kComputeWaves = WG::cw;
   using TIn = std::conditional_t<U8, unsigned char, float>;
   constexpr int ES = (int)sizeof(TIn);    // bytes per image element in HBM
   constexpr int N = NP<TT>::n;
@@ -376,6 +381,10 @@ __global__ __launch_bounds__((IterCfg<C, U8>::block), (IterCfg<C, U8>::loader ? 
   const int x_t0 = tx * kTileW;
   const int x = x_t0 + lane;
   const float xf = (float)x;
+  // (Dealing the chunks of two vertically adjacent tiles alternately to their two workgroups, so that the 9 footprint rows
+  //  consecutive chunks share are asked for at about the same time, was built and measured: HBM traffic UP, 1.18x instead
+  //  of 1.12x the algorithmic bytes for one channel, 1.78x instead of 1.61x for three, times unchanged --
+  //  profiles/r03_ablation.txt.)
   const int y_begin = ty * a.tile_h;
   const int y_end = min(H, y_begin + a.tile_h);
   const int nchunks = (y_end - y_begin + CH - 1) / CH;  // <= 32: one lane plans one chunk (tile_h <= 32 * CH, host-checked)
