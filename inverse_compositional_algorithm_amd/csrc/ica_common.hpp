@@ -25,8 +25,11 @@ namespace ica {
 #ifndef ICA_CH     // image rows per chunk, one channel, no loader wave
 #define ICA_CH 32
 #endif
-#ifndef ICA_CH3    // image rows per chunk, three channels (a 32-row tile of three channels does not fit the LDS)
-#define ICA_CH3 16
+#ifndef ICA_CSEQ   // 1 (an experiment, measured slower): three channels staged one at a time (ica_iterate.hpp, TileCfg::seq)
+#define ICA_CSEQ 0
+#endif
+#ifndef ICA_CH3    // image rows per chunk, three channels (three RESIDENT channels only fit the LDS as 16-row chunks)
+#define ICA_CH3 (ICA_CSEQ ? 32 : 16)
 #endif
 // rows per chunk of the kernel that runs a level of `channels` channels stored as uint8 (`u8`) or float32
 constexpr int iter_chunk_rows(int channels, bool u8) {

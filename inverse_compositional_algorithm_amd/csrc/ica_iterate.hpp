@@ -58,9 +58,6 @@
 #ifndef ICA_POS_LINEAR   // interior band, homography: displacement from per-column polynomials in y (fewer instructions)
 #define ICA_POS_LINEAR 0
 #endif
-#ifndef ICA_CH3    // image rows per chunk, three channels (a 32-row tile of three channels does not fit the LDS)
-#define ICA_CH3 16
-#endif
 
 #include "ica_common.hpp"
 
@@ -151,13 +148,24 @@ template <int C, bool LOADER = false> struct TileCfg {
   // uses the same chunk (bit-identical results need the same rows in the same waves); with its staging area it holds
   // 28.6 KB, 5 workgroups per CU, and is still 4 % faster than with 16-row chunks.
   // Three channels: 16 rows, one 39.5 KB tile, 4 workgroups per CU.
+  // Three channels, ICA_CSEQ = 1 (an experiment, off by default): the tile holds ONE channel at a time, at the one-channel
+  // geometry (32-row chunks, 22.9 KB).  A chunk is walked in three passes -- copy channel c, run the band on it -- with the
+  // per-pixel sums over the channels (gx, gy, sxx, sxy, syy, t^2: six registers per row of the wave's band) carried across
+  // the passes; rho' and the moments follow the third.  The idea: three RESIDENT channels only fit as 16-row chunks, whose
+  // 9 + 2 halo rows per chunk cost 1.61x the algorithmic bytes from HBM.  Measured on 256 pairs of 1080 x 1920 x 3
+  // (profiles/r03_ablation.txt): traffic 1.61x -> 1.28x, but 4310 us against 3640 us for robust homography, 1866 against
+  // 1230 us for the Hessian pass, L2 rhs passes unchanged -- three copy / barrier phases per 32 rows instead of two, 38 %
+  // more vector instructions (positions and weights once per pass), and the same LDS reads, which are what this kernel is
+  // bound by (57 dwords per pixel row).
+  static constexpr bool seq = (C == 3) && (ICA_CSEQ != 0);
+  static constexpr int lc = seq ? 1 : C;               // channels resident in the tile
   static constexpr int ch = LOADER ? ICA_CH_LOADER : (C == 1) ? ICA_CH : ICA_CH3;
   static constexpr int rw = ch / compute_waves(C);
   static_assert(ch % compute_waves(C) == 0, "a chunk is split evenly among the computing waves");
   static constexpr int p2 = 80, r2 = ch + 9;           // I2 footprint buffer: pitch (floats) x rows
   static constexpr int p1 = 72, r1 = ch + 2;           // I1 buffer: columns x_t0-4 .. x_t0+67, rows yc0-1 .. yc0+ch
   static constexpr int nbuf = LOADER ? 2 : (C == 1) ? ICA_NBUF : 1;
-  static constexpr int buf_floats = C * (p2 * r2 + p1 * r1);
+  static constexpr int buf_floats = lc * (p2 * r2 + p1 * r1);
 };
 
 // 4 bytes per lane, global -> LDS at (wave-uniform) lds_base + 4*lane: rows that are not 16-byte aligned
@@ -308,9 +316,11 @@ __global__ __launch_bounds__((IterCfg<C, U8>::block), (IterCfg<C, U8>::loader ? 
   using ML = MomLayout<TT>;
   using TC = TileCfg<C, kLoader>;
   constexpr int CH = TC::ch, RW = TC::rw, P2 = TC::p2, R2 = TC::r2, P1 = TC::p1, R1 = TC::r1;
+  constexpr bool kSeq = TC::seq;                          // one channel in the tile at a time (see TileCfg)
+  constexpr int LC = TC::lc, kPasses = kSeq ? C : 1;
   constexpr int NBUF = U8 ? 1 : TC::nbuf;                 // float tiles
   constexpr int kStageFloats = U8 ? TC::buf_floats / 4 : 0;  // uint8 staging area, in floats (4 pixels each)
-  static_assert(TC::buf_floats % 16 == 0 && (C * P2 * R2) % 4 == 0, "tile regions must be whole 16-byte groups");
+  static_assert(TC::buf_floats % 16 == 0 && (LC * P2 * R2) % 4 == 0, "tile regions must be whole 16-byte groups");
   constexpr int NMOM = ML::nmom;
   constexpr unsigned kPitchBits = P2 == 80 ? 0x43a00000u : P2 == 96 ? 0x43c00000u : 0u;  // (float)(P2 * 4)
   static_assert(kPitchBits != 0, "add the bit pattern of (float)(P2 * 4)");
@@ -529,15 +539,16 @@ __global__ __launch_bounds__((IterCfg<C, U8>::block), (IterCfg<C, U8>::loader ? 
   //  the 25 I2 rows, 2 of the 18 I1 rows -- was built and measured: a quarter fewer L1 requests, but 9 % MORE time;
   //  the move and its dependency sit in front of the copies.  profiles/r02_ablation.txt)
   const bool copies = !kLoader || wave >= kComputeWaves;   // (with loader waves: they alone copy)
-  auto issue_impl = [&](int k, int buf) {
-#if defined(ICA_ABLATE) && (ICA_ABLATE & 2)   // (ICA_ABLATE is a set of bits: 1 copies only, 2 no copies, 4 lane-linear taps, 8 no barriers)
+  auto issue_impl = [&](int k, int buf, int pass) {   // pass: the channel to copy (channel-sequential tiles only)
+#if defined(ICA_ABLATE) && (ICA_ABLATE & 2)   // (ICA_ABLATE is a set of bits: 1 copies only, 2 no copies, 4 lane-linear taps, 8 no barriers, 16 half the tap reads, 64 no Hessian moments)
     return;  // timing-only build: no LDS-DMA
 #endif
     const int px = plan_px(k), y_lo = plan_ylo(k);
     // destination: the float tile `buf`, or (U8) the staging area behind the tile, laid out like the tile, in bytes
     TIn* b2 = U8 ? reinterpret_cast<TIn*>(lds + NBUF * TC::buf_floats) : reinterpret_cast<TIn*>(lds + buf * TC::buf_floats);
-    TIn* b1 = b2 + C * P2 * R2;
+    TIn* b1 = b2 + LC * P2 * R2;
     const int yc0 = y_begin + k * CH;
+    [[maybe_unused]] const unsigned pass_off = kSeq ? (unsigned)((size_t)pass * plane * ES) : 0u;
     if (w4) {
       // a skipped (all-frame) chunk still issues its copies, with every lane out of range (the tile is zero-filled)
       const bool skip = (px & (1 << 29)) != 0;
@@ -555,8 +566,8 @@ __global__ __launch_bounds__((IterCfg<C, U8>::block), (IterCfg<C, U8>::loader ? 
           asm volatile("" : "+s"(u));  // (opaque: the sum with off1 is formed here, not hoisted out of the chunk loop into a register)
           const unsigned o = off1 + u;  // a poisoned offset stays out of range
 #pragma unroll
-          for (int c = 0; c < C; ++c)
-            ICA_LDS_DMA(U8, rs1, dst + c * P1 * R1, o + (unsigned)(c * plane * ES));
+          for (int c = 0; c < LC; ++c)
+            ICA_LDS_DMA(U8, rs1, dst + c * P1 * R1, o + pass_off + (unsigned)(c * plane * ES));
         }
       }
       if constexpr (kB) {
@@ -565,8 +576,9 @@ __global__ __launch_bounds__((IterCfg<C, U8>::block), (IterCfg<C, U8>::loader ? 
         const int bh = stage ? plan_bh(k) : 0;
         // rows beyond the footprint fall outside this descriptor (a chunk that is not staged gets 0 rows) and are
         // zero-filled
+        // (channel-sequential: the descriptor ends behind the footprint's last row of THIS channel)
         const auto rs2 = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)I2, 0, bh ? (int)(((size_t)(C - 1) * plane + (size_t)(y_lo + bh) * W) * ES) : 0, 0x00020000);
+            (void*)I2, 0, bh ? (int)(((size_t)(kSeq ? pass : C - 1) * plane + (size_t)(y_lo + bh) * W) * ES) : 0, 0x00020000);
         const unsigned base2 = (unsigned)((y_lo * W + x_lo) * ES);
 #pragma unroll
         for (int qq = 0; qq < (NQ2 + kCopyWaves - 1) / kCopyWaves; ++qq) {
@@ -578,8 +590,8 @@ __global__ __launch_bounds__((IterCfg<C, U8>::block), (IterCfg<C, U8>::loader ? 
             asm volatile("" : "+s"(u));
             const unsigned o = off2 + u;  // all P2 columns of a row are copied (a few more than needed)
 #pragma unroll
-            for (int c = 0; c < C; ++c)
-              ICA_LDS_DMA(U8, rs2, dst + c * P2 * R2, o + (unsigned)(c * plane * ES));
+            for (int c = 0; c < LC; ++c)
+              ICA_LDS_DMA(U8, rs2, dst + c * P2 * R2, o + pass_off + (unsigned)(c * plane * ES));
           }
         }
       }
@@ -589,8 +601,8 @@ __global__ __launch_bounds__((IterCfg<C, U8>::block), (IterCfg<C, U8>::loader ? 
         const int yy = yc0 - 1 + r;
         if (yy < 0 || yy >= H) continue;
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-          const float* src = I1 + c * plane + (size_t)yy * W + (x_t0 - 4);
+        for (int c = 0; c < LC; ++c) {
+          const float* src = I1 + (size_t)(kSeq ? pass : c) * plane + (size_t)yy * W + (x_t0 - 4);
           float* dst = b1 + c * P1 * R1 + r * P1;
           if ((x_t0 - 4 + lane >= 0) & (x_t0 - 4 + lane < W)) glds4(src + lane, dst);
           if ((lane < P1 - 64) & (x_t0 + 60 + lane < W)) glds4(src + 64 + lane, dst + 64);
@@ -602,8 +614,8 @@ __global__ __launch_bounds__((IterCfg<C, U8>::block), (IterCfg<C, U8>::loader ? 
           const int yy = y_lo + r;
           if (yy >= H) break;
 #pragma unroll
-          for (int c = 0; c < C; ++c) {
-            const float* src = I2 + c * plane + (size_t)yy * W + x_lo;
+          for (int c = 0; c < LC; ++c) {
+            const float* src = I2 + (size_t)(kSeq ? pass : c) * plane + (size_t)yy * W + x_lo;
             float* dst = b2 + c * P2 * R2 + r * P2;
             if (x_lo + lane < W) glds4(src + lane, dst);
             if ((lane < P2 - 64) & (x_lo + 64 + lane < W)) glds4(src + 64 + lane, dst + 64);
@@ -613,8 +625,8 @@ __global__ __launch_bounds__((IterCfg<C, U8>::block), (IterCfg<C, U8>::loader ? 
     }
   };
 
-  auto issue = [&](int k, int buf) {
-    if (copies) issue_impl(k, buf);
+  auto issue = [&](int k, int buf, int pass = 0) {
+    if (copies) issue_impl(k, buf, pass);
   };
   if (!w4) {  // the dword copy path skips out-of-image lanes instead of zero-filling them: start from finite LDS
     for (int i = threadIdx.x; i < kLdsFloats; i += kIterBlock) lds[i] = 0.f;
@@ -635,7 +647,7 @@ __global__ __launch_bounds__((IterCfg<C, U8>::block), (IterCfg<C, U8>::loader ? 
   static_assert(NBUF == 1 || NBUF == 2, "one or two staging buffers");
   // U8: staging area -> float tile, 4 pixels per thread and step; rows whose width is not a multiple of 4 pixels (no
   // whole-group copies) are read straight from memory, element by element (cold path: odd widths at level 0)
-  [[maybe_unused]] auto expand = [&](int k) {
+  [[maybe_unused]] auto expand = [&](int k, [[maybe_unused]] int pass) {
     if (w4) {
       const unsigned* s32 = reinterpret_cast<const unsigned*>(lds + TC::buf_floats);
       for (int e = threadIdx.x; e < TC::buf_floats / 4; e += kIterBlock) {
@@ -647,9 +659,10 @@ __global__ __launch_bounds__((IterCfg<C, U8>::block), (IterCfg<C, U8>::loader ? 
     } else {
       const int px = plan_px(k), y_lo = plan_ylo(k), x_lo = px & 0xFFFFF, yc0 = y_begin + k * CH;
       for (int e = threadIdx.x; e < TC::buf_floats; e += kIterBlock) {
-        const bool two = e < C * P2 * R2;                  // I2 footprint region, else I1 tile region
-        const int f = two ? e : e - C * P2 * R2, pitch = two ? P2 : P1, rows = two ? R2 : R1;
-        const int c = f / (pitch * rows), g = f - c * pitch * rows, r = g / pitch, col = g - r * pitch;
+        const bool two = e < LC * P2 * R2;                 // I2 footprint region, else I1 tile region
+        const int f = two ? e : e - LC * P2 * R2, pitch = two ? P2 : P1, rows = two ? R2 : R1;
+        const int cl = f / (pitch * rows), g = f - cl * pitch * rows, r = g / pitch, col = g - r * pitch;
+        const int c = kSeq ? pass : cl;                    // image channel
         const int yy = two ? y_lo + r : yc0 - 1 + r, xx = two ? x_lo + col : x_t0 - 4 + col;
         const TIn* img = two ? I2 : I1;
         const bool in = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W) & (two ? (kB && (px & (1 << 30)) != 0) : true);
@@ -680,18 +693,137 @@ __global__ __launch_bounds__((IterCfg<C, U8>::block), (IterCfg<C, U8>::loader ? 
   {
     const unsigned all = cls_mask[0] | cls_mask[1] | cls_mask[2];
     const int k0 = kWalk == 1 ? (all ? __builtin_ctz(all) : -1) : first_from(0);
-    if (k0 >= 0 && ((U8 && w4) || (!U8 && NBUF == 2))) issue(k0, 0);
+    if (k0 >= 0 && ((U8 && w4 && !kSeq) || (!U8 && NBUF == 2))) issue(k0, 0);
   }
+  // the lane's y-moments from a pixel's channel sums (what accumulate() does behind its channel loops)
+  [[maybe_unused]] auto finish_seq = [&](float w, const float* s6, float yf) {
+    [[maybe_unused]] const float y2 = yf * yf;
+    if constexpr (kB) {
+      float gx = s6[0], gy = s6[1];
+      if constexpr (kH) { gx *= w; gy *= w; }
+      m32[ML::ogx] += gx;
+      if constexpr (ML::mbx >= 1) m32[ML::ogx + 1] = fmaf(gx, yf, m32[ML::ogx + 1]);
+      m32[ML::ogy] += gy;
+      if constexpr (ML::mby >= 1) m32[ML::ogy + 1] = fmaf(gy, yf, m32[ML::ogy + 1]);
+      if constexpr (ML::mby >= 2) m32[ML::ogy + 2] = fmaf(gy, y2, m32[ML::ogy + 2]);
+    }
+    if constexpr (kH) {
+      const float sxx = s6[2] * w, sxy = s6[3] * w, syy = s6[4] * w;
+      float yp[5];
+      yp[0] = 1.0f; yp[1] = yf; yp[2] = y2; yp[3] = y2 * yf; yp[4] = y2 * y2;
+#pragma unroll
+      for (int b = 0; b < 5; ++b) {
+        if (b < ML::nxx) m32[ML::oxx + b] = (b == 0) ? m32[ML::oxx] + sxx : fmaf(sxx, yp[b], m32[ML::oxx + b]);
+        if (b < ML::nxy) m32[ML::oxy + b] = (b == 0) ? m32[ML::oxy] + sxy : fmaf(sxy, yp[b], m32[ML::oxy + b]);
+        if (b < ML::nyy) m32[ML::oyy + b] = (b == 0) ? m32[ML::oyy] + syy : fmaf(syy, yp[b], m32[ML::oyy + b]);
+      }
+    }
+  };
   // one chunk: ring protocol, then the band of its class.  `next` = the chunk that follows in walking order (-1: none).
   auto step = [&](auto cls_c, const int k, const int next) {
     constexpr int CLS = decltype(cls_c)::value;
+    // channel-sequential tiles: the sums over the channels of each pixel of this wave's band, carried from pass to pass
+    // ([0] gx = sum Ix DI, [1] gy, [2] sxx = sum Ix^2, [3] sxy, [4] syy, [5] t^2 = sum DI^2; gradients doubled as elsewhere)
+    [[maybe_unused]] float sg[kSeq ? RW : 1][6];
+    if constexpr (kSeq) {
+      // A careful chunk (border pixels whose footprint leaves I2, a partial chunk, a footprint too large to stage) is
+      // walked ONCE, all channels per pixel, straight from memory through the cache: it needs every test of the reference's
+      // pixel masks and the float64 re-evaluation, code that is kept small (rolled) and so cannot carry sums from pass to
+      // pass in registers.  It touches neither tile nor staging area, so it needs no copy and no barrier.
+      const bool careful = CLS == 2 || (CLS == 3 && !(((cls_mask[0] | cls_mask[1]) >> k) & 1));
+      if (careful) {
+        const int yb0 = y_begin + k * CH + wave * RW;
+        [[maybe_unused]] const float cx = fmaf(A[0], xf, A[2]), cy = fmaf(A[3], xf, A[5]), gxc = A[6] * xf;
+        const int xc = min(x, W - 1), xl = max(xc - 1, 0), xr = min(xc + 1, W - 1);
+#pragma unroll 1
+        for (int i = 0; i < RW; ++i) {
+          const int y = yb0 + i;  // wave-uniform
+          const bool row_live = (y < y_end) & !(frame_on & ((y < a.delta) | (y >= H - a.delta)));
+          const float rmy = ((y >= 1) & (y <= H - 2)) ? 1.0f : 0.0f;  // ref :82: zero y-derivative on the border rows
+          const bool live = col_ok & row_live;
+          const float yf = (float)y;
+          const int yc = min(y, H - 1), yu = max(yc - 1, 0), yd = min(yc + 1, H - 1);
+          float wx[4], wy[4];
+          [[maybe_unused]] bool valid = false;
+          [[maybe_unused]] size_t toff = 0;
+          if constexpr (kB) {
+            float dxw, dyw;
+            displacement_col<kProj>(A, cx, cy, gxc, xf, yf, dxw, dyw);
+            float flx = floorf(dxw), fly = floorf(dyw);
+            float fx = dxw - flx, fy = dyw - fly;
+            int ix = (int)flx, iy = (int)fly;
+            const bool near_x = live & (fminf(fx, 1.0f - fx) < kNearInteger), near_y = live & (fminf(fy, 1.0f - fy) < kNearInteger);
+#ifndef ICA_NO_EXACT
+            if (near_x) exact_axis<TT, 0>(a.p + (size_t)pair * 8, ident, x, y, x, ix, fx);
+            if (near_y) exact_axis<TT, 1>(a.p + (size_t)pair * 8, ident, x, y, y, iy, fy);
+#endif
+            const int ux = ix + xm1, uy = iy + (y - 1);
+            valid = live & can_sample & ((unsigned)ux <= ux_max) & ((unsigned)uy <= uy_max);
+            toff = valid ? (size_t)uy * W + ux : 0;
+            keys_weights(fx, wx);
+            keys_weights(fy, wy);
+          }
+          float s6[6];
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            const TIn* i1c = I1 + (size_t)c * plane;
+            // (clamped coordinates: where a neighbour does not exist its difference is masked, any finite value will do)
+            const float mid = (float)i1c[(size_t)yc * W + xc];
+            const float ix2 = ((float)i1c[(size_t)yc * W + xr] - (float)i1c[(size_t)yc * W + xl]) * cmx;
+            const float iy2 = ((float)i1c[(size_t)yd * W + xc] - (float)i1c[(size_t)yu * W + xc]) * rmy;
+            float di = 0.f;
+            if constexpr (kB) {
+              const TIn* q = I2 + (size_t)c * plane + toff;
+              float v = 0.f;
+              if (valid) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  const TIn* rp = q + (size_t)r * W;
+                  float s = wx[0] * (float)rp[0];
+                  s = __builtin_fmaf(wx[1], (float)rp[1], s);
+                  s = __builtin_fmaf(wx[2], (float)rp[2], s);
+                  s = __builtin_fmaf(wx[3], (float)rp[3], s);
+                  v = (r == 0) ? wy[0] * s : __builtin_fmaf(wy[r], s, v);
+                }
+              }
+              const float d = __builtin_amdgcn_fmed3f(v, lo, hi) - mid;     // clip (skimage warp), ref :114
+              di = (valid & (fabsf(d) <= 3.0e38f)) ? d : 0.0f;              // NaN / outside -> 0 (io.py:99)
+            }
+            if constexpr (!kH) di *= live ? 1.0f : 0.0f;   // unweighted sums: the mask goes into the residual
+            if constexpr (kB) {
+              s6[0] = (c == 0) ? ix2 * di : fmaf(ix2, di, s6[0]);
+              s6[1] = (c == 0) ? iy2 * di : fmaf(iy2, di, s6[1]);
+            }
+            if constexpr (kH) {
+              s6[2] = (c == 0) ? ix2 * ix2 : fmaf(ix2, ix2, s6[2]);
+              s6[3] = (c == 0) ? ix2 * iy2 : fmaf(ix2, iy2, s6[3]);
+              s6[4] = (c == 0) ? iy2 * iy2 : fmaf(iy2, iy2, s6[4]);
+            }
+            if constexpr (kRobust) s6[5] = (c == 0) ? di * di : fmaf(di, di, s6[5]);
+          }
+          float w = live ? 1.0f : 0.0f;  // pixels in the NaN frame contribute nothing (derivatives.py:84)
+          if constexpr (kRobust) w = live ? rho_prime_t<RT>(s6[5], lam2) : 0.0f;  // rho'(0) where the warp is outside
+          finish_seq(w, s6, yf);
+        }
+        return;
+      }
+    }
+   auto one_pass = [&](auto pass_c) {
+    constexpr int PC = decltype(pass_c)::value;   // the channel in the tile (channel-sequential), else 0
     const int buf = (NBUF >= 2) ? ring : 0;
     if constexpr (U8) {
+      // (channel-sequential: a chunk's first channel is asked for here, not under the previous chunk -- that one may be
+      //  a careful chunk, which runs without the tile; the staging area is free: its last user expanded it a band ago)
+      if constexpr (kSeq && PC == 0) { if (w4) issue(k, 0, 0); }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();   // chunk k's bytes are in the staging area; everyone is done with the float tile
-      expand(k);
+      expand(k, PC);
       __syncthreads();                // the float tile holds chunk k; the staging area is free
-      if (w4 && next >= 0) issue(next, 0);
+      if constexpr (kSeq) {
+        if (w4 && PC + 1 < kPasses) issue(k, 0, PC + 1);   // the next channel's bytes, under this channel's band
+      } else {
+        if (w4 && next >= 0) issue(next, 0);
+      }
     } else if (NBUF == 1) {
 #ifdef ICA_STAMP
       const long long s0 = clock64();
@@ -702,7 +834,7 @@ __global__ __launch_bounds__((IterCfg<C, U8>::block), (IterCfg<C, U8>::loader ? 
 #ifdef ICA_STAMP
       const long long s1 = clock64();
 #endif
-      issue(k, 0);
+      issue(k, 0, PC);
 #ifdef ICA_STAMP
       const long long s2 = clock64();
 #endif
@@ -724,7 +856,7 @@ __global__ __launch_bounds__((IterCfg<C, U8>::block), (IterCfg<C, U8>::loader ? 
     [[maybe_unused]] const bool staged = (px & (1 << 30)) != 0;
     const int x_lo = px & 0xFFFFF;
     const float* b2 = lds + buf * TC::buf_floats;
-    const float* b1 = b2 + C * P2 * R2;
+    const float* b1 = b2 + LC * P2 * R2;
     const int yc0 = y_begin + k * CH;
     const int yb0 = yc0 + wave * RW;
     const float* i1p = b1 + (wave * RW) * P1 + lane + 4;  // row yb0-1 of this lane's column
@@ -757,7 +889,11 @@ __global__ __launch_bounds__((IterCfg<C, U8>::block), (IterCfg<C, U8>::loader ? 
         if constexpr (ML::mby >= 1) m32[ML::ogy + 1] = fmaf(gy, yf, m32[ML::ogy + 1]);
         if constexpr (ML::mby >= 2) m32[ML::ogy + 2] = fmaf(gy, y2, m32[ML::ogy + 2]);
       }
+#if defined(ICA_ABLATE) && (ICA_ABLATE & 64)   // timing-only build: no Hessian moments (15 vector instructions per pixel fewer)
+      if constexpr (false) {
+#else
       if constexpr (kH) {
+#endif
         float sxx = 0.f, sxy = 0.f, syy = 0.f;
         if constexpr (kFoldW) {
           sxx = wix * ix2[0];
@@ -931,10 +1067,15 @@ __global__ __launch_bounds__((IterCfg<C, U8>::block), (IterCfg<C, U8>::loader ? 
             float v = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              float s = wx[0] * q[r * P2];
-              s = __builtin_fmaf(wx[1], q[r * P2 + 1], s);
-              s = __builtin_fmaf(wx[2], q[r * P2 + 2], s);
-              s = __builtin_fmaf(wx[3], q[r * P2 + 3], s);
+#if defined(ICA_ABLATE) && (ICA_ABLATE & 16)   // timing-only build: half the tap reads (footprint rows 2, 3 take the values of rows 0, 1)
+              const int rr = r & 1;
+#else
+              const int rr = r;
+#endif
+              float s = wx[0] * q[rr * P2];
+              s = __builtin_fmaf(wx[1], q[rr * P2 + 1], s);
+              s = __builtin_fmaf(wx[2], q[rr * P2 + 2], s);
+              s = __builtin_fmaf(wx[3], q[rr * P2 + 3], s);
               v = (r == 0) ? wy[0] * s : __builtin_fmaf(wy[r], s, v);
             }
             di[c] = __builtin_amdgcn_fmed3f(v, lo, hi_v) - cm[c];  // clip (skimage warp), ref :114
@@ -1068,9 +1209,113 @@ __global__ __launch_bounds__((IterCfg<C, U8>::block), (IterCfg<C, U8>::loader ? 
         accumulate(w, ix2, iy2, di, yf);
       }
     };
+
+    // ---------------------------------------------------------------------------------------------------------
+    // Channel-sequential tiles (three channels, TileCfg::seq): the same two bands, run once per channel PC on the
+    // channel the tile holds.  The sampling position and the Keys weights are formed again in every pass (the vector ALU
+    // has the room: this kernel is bound by its copies and its LDS reads), the sums over the channels live in sg[][],
+    // in the order of the resident-channel bands (channel 0 first), and the weight, its products and the moments follow
+    // the last channel.
+    // ---------------------------------------------------------------------------------------------------------
+    // channel PC's terms of a pixel's sums (first channel: products, later ones: multiply-adds, as in accumulate())
+    [[maybe_unused]] auto add_channel = [&](float* s6, float ix2, float iy2, float di) {
+      if constexpr (kB) {
+        s6[0] = (PC == 0) ? ix2 * di : fmaf(ix2, di, s6[0]);
+        s6[1] = (PC == 0) ? iy2 * di : fmaf(iy2, di, s6[1]);
+      }
+      if constexpr (kH) {
+        s6[2] = (PC == 0) ? ix2 * ix2 : fmaf(ix2, ix2, s6[2]);
+        s6[3] = (PC == 0) ? ix2 * iy2 : fmaf(ix2, iy2, s6[3]);
+        s6[4] = (PC == 0) ? iy2 * iy2 : fmaf(iy2, iy2, s6[4]);
+      }
+      if constexpr (kRobust) s6[5] = (PC == 0) ? di * di : fmaf(di, di, s6[5]);
+    };
+    [[maybe_unused]] auto band_fast_seq = [&](auto masked_c) {
+      constexpr bool MASKED = decltype(masked_c)::value;
+      const int lds_b2 = (int)(unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)b2;
+      const float tap0f = (float)(lds_b2 + ((yb0 - 1 - y_lo) * P2 + (xm1 - x_lo)) * 4);
+      // (volatile: the three passes form the same positions and weights from the same inputs -- left to itself the compiler
+      //  computes them once for the whole chunk and keeps them in scratch memory across the passes)
+      float yf0 = (float)yb0;
+      asm volatile("" : "+v"(yf0));
+      [[maybe_unused]] const float cx = fmaf(A[0], xf, A[2]), cy = fmaf(A[3], xf, A[5]), gxc = A[6] * xf, nxf = -xf;
+      [[maybe_unused]] const float a1v = pin_vgpr(A[1]), a4v = pin_vgpr(A[4]), a7v = pin_vgpr(A[7]);
+      [[maybe_unused]] const float hi_v = pin_vgpr(hi), lam2_v = pin_vgpr(lam2);
+      float cu, cm = i1p[0], cd = i1p[P1];
+#pragma unroll
+      for (int i = 0; i < RW; ++i) {
+        const float yf = i == 0 ? yf0 : yf0 + (float)i;
+        [[maybe_unused]] bool live = true;
+        if constexpr (MASKED) {
+          const int y = yb0 + i;  // wave-uniform
+          live = col_ok & (y < y_end) & !((y < a.delta) | (y >= H - a.delta));
+        }
+        const float* q1 = i1p + (i + 1) * P1;
+        cu = cm; cm = cd; cd = q1[P1];
+        const float ix2 = q1[1] - q1[-1], iy2 = cd - cu;
+        float di = 0.f;
+        if constexpr (kB) {
+          float dxw, dyw;
+          if constexpr (kProj) {
+            dxw = fmaf(a1v, yf, cx); dyw = fmaf(a4v, yf, cy);
+            const float g = fmaf(a7v, yf, gxc);
+            const float r = rcp_nr(1.0f + g);
+            dxw = fmaf(nxf, g, dxw) * r;
+            dyw = fmaf(-yf, g, dyw) * r;
+          } else {
+            dxw = fmaf(a1v, yf, cx); dyw = fmaf(a4v, yf, cy);
+          }
+          const float flx = floorf(dxw), fly = floorf(dyw);
+          const float fx = dxw - flx, fy = dyw - fly;
+          float af;
+          asm("v_fmamk_f32 %0, %1, %3, %2" : "=v"(af) : "v"(fly), "v"(tap0f), "n"(kPitchBits));
+          af = fmaf(flx, 4.0f, af);
+          unsigned addr = (unsigned)((int)af + i * P2 * 4);
+          if (i > 0) asm("" : "+v"(addr));
+          float wx[4], wy[4];
+          keys_weights(fx, wx);
+          keys_weights(fy, wy);
+          const __attribute__((address_space(3))) float* q = (const __attribute__((address_space(3))) float*)(uintptr_t)addr;
+          float v = 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float sr = wx[0] * q[r * P2];
+            sr = __builtin_fmaf(wx[1], q[r * P2 + 1], sr);
+            sr = __builtin_fmaf(wx[2], q[r * P2 + 2], sr);
+            sr = __builtin_fmaf(wx[3], q[r * P2 + 3], sr);
+            v = (r == 0) ? wy[0] * sr : __builtin_fmaf(wy[r], sr, v);
+          }
+          di = __builtin_amdgcn_fmed3f(v, lo, hi_v) - cm;  // clip (skimage warp), ref :114
+          if constexpr (MASKED) di = live ? di : 0.0f;
+        }
+        add_channel(sg[i], ix2, iy2, di);
+        if constexpr (PC + 1 < kPasses) {
+          // (the sums are not used before the last pass: without this the compiler defers the whole arithmetic to that
+          //  pass and carries the raw LDS values of the earlier ones -- 19 per pixel -- through scratch memory)
+          if constexpr (kB) asm volatile("" : "+v"(sg[i][0]), "+v"(sg[i][1]));
+          if constexpr (kH) asm volatile("" : "+v"(sg[i][2]), "+v"(sg[i][3]), "+v"(sg[i][4]));
+          if constexpr (kRobust) asm volatile("" : "+v"(sg[i][5]));
+        }
+        if constexpr (PC == kPasses - 1) {
+          float w = 1.0f;
+          if constexpr (kRobust) w = rho_prime_t<RT>(sg[i][5], lam2_v);
+          if constexpr (MASKED && kH) w = live ? w : 0.0f;  // pixels in the NaN frame contribute nothing (derivatives.py:84)
+          finish_seq(w, sg[i], yf);
+        }
+#if ICA_ROW_FENCE
+        if ((i + 1) % ICA_ROW_FENCE == 0) __builtin_amdgcn_sched_barrier(0);
+#endif
+      }
+    };
 #if defined(ICA_ABLATE) && (ICA_ABLATE & 1)
     if (a.delta < 0)  // timing-only build: staging and barriers only
 #endif
+    if constexpr (kSeq) {   // (careful chunks never get here: step() runs them in one pass, without the tile)
+      if constexpr (CLS == 0) band_fast_seq(std::false_type{});
+      else if constexpr (CLS == 1) band_fast_seq(std::true_type{});
+      else if ((cls_mask[0] >> k) & 1) band_fast_seq(std::false_type{});
+      else band_fast_seq(std::true_type{});
+    } else
     if (!kLoader || wave < kComputeWaves) {
       if constexpr (CLS == 0) band_fast(std::false_type{});
       else if constexpr (CLS == 1) band_fast(std::true_type{});
@@ -1086,6 +1331,14 @@ __global__ __launch_bounds__((IterCfg<C, U8>::block), (IterCfg<C, U8>::loader ? 
 #ifdef ICA_STAMP
     if constexpr (!U8 && NBUF == 1) stamp[3] += clock64();
 #endif
+   };
+    if constexpr (kSeq) {
+      one_pass(IC<0>{});
+      one_pass(IC<1>{});
+      one_pass(IC<2>{});
+    } else {
+      one_pass(IC<0>{});
+    }
   };
   // Ring protocol (two tiles): chunk `next` is in flight while chunk k is computed.  A wave's copies retire in order;
   // the barrier makes every wave's part visible, and also means everyone has finished reading the chunk before k,
