@@ -298,6 +298,8 @@ def measure(args, info, sharding, cfg_id, steps, warmup, D, batch=0, storage="f3
                first_ms=0.0, n_prof=0, res=None, latency=0.0, lvl_ms=[0.0] * ns, lvl_bytes=[0.0] * ns, lvl_n=[0] * ns,
                lvl_units=[0] * ns, lvl_first_ms=[0.0] * ns, lvl_first_n=[0] * ns, lvl_wh=[(0, 0)] * ns)
 
+    clock = dict(samples=[])   # shader clock of each event-bracketed step (measured inside the iteration kernel)
+
     def run_steps(n_steps, timed):
         counter = iter(range(n_steps))
 
@@ -341,6 +343,8 @@ def measure(args, info, sharding, cfg_id, steps, warmup, D, batch=0, storage="f3
                             acc["s0_bytes"] += r.stats["iter_kernel_bytes"][0]
                             acc["s0_n"] += r.stats["iter_launches"][0]
                             acc["first_ms"] += sum(r.stats["first_kernel_ms"])
+                            if r.stats.get("shader_clock_ghz", 0.0) > 0.0:
+                                clock["samples"].append(r.stats["shader_clock_ghz"])
                             for s in range(ns):
                                 acc["lvl_ms"][s] += r.stats["iter_kernel_ms"][s]
                                 acc["lvl_bytes"][s] += r.stats["iter_kernel_bytes"][s]
@@ -364,37 +368,16 @@ def measure(args, info, sharding, cfg_id, steps, warmup, D, batch=0, storage="f3
     # the dominant kernel = the steady-state iteration kernel (one template instantiation), ALL its launches of the
     # event-bracketed steps at every pyramid scale -- the same set rocprofv3 --stats averages under that kernel's name
     run_steps(max(warmup, D if D > 1 else 0), timed=False)
-    # the shader clock the chip sustains under this load: one wave on a second context / stream compares s_memtime with
-    # the constant 100 MHz counter, 20 ms at a time, for as long as the timed region lasts (rank 0's GPU)
-    clock = dict(samples=[], stop=False)
-    probe = None
-    # (a probe wave holds one hardware queue while it runs: short probes with pauses in between, and none at all beside
-    #  more than two solves in flight -- with four streams a solve's stream ends up behind the probe's)
-    if os.environ.get("BENCH_CLOCK", "1") == "1" and D <= 2:
-        probe_eng = IcaEngine(local)
-        probe_stream = torch.cuda.Stream(device=eng.device)
-
-        def probe_loop():
-            torch.cuda.set_device(local)
-            with torch.cuda.stream(probe_stream):
-                while not clock["stop"]:
-                    try:
-                        clock["samples"].append(probe_eng.shader_clock_ghz(3000))
-                    except Exception:
-                        return
-                    time.sleep(0.012)
-        probe = threading.Thread(target=probe_loop)
+    # The shader clock the chip sustains under this load is measured INSIDE the iteration kernel of the event-bracketed
+    # steps (ica_stats.shader_clock_ghz: cycles / 100 MHz ticks of one workgroup's lifetime in the middle of every
+    # launch).  (Until round 3 a probe wave on a second stream measured it beside the timed region; when the two streams
+    # happened to share a hardware queue the probe's 3 ms in every 15 serialised with the solve -- seen once as a step
+    # 20 % longer at the idle clock, 2.41 GHz -- so nothing but the solves runs in the timed region now.)
     sharding.barrier(info, eng.device)
-    if probe:
-        probe.start()
     t0 = time.perf_counter()
     run_steps(steps, timed=True)
     sharding.barrier(info, eng.device)
     dt = time.perf_counter() - t0
-    if probe:
-        clock["stop"] = True
-        probe.join()
-        probe_eng.close()
     res = acc["res"]
 
     # solution quality on this shard (not part of the timed region)
@@ -423,7 +406,8 @@ def measure(args, info, sharding, cfg_id, steps, warmup, D, batch=0, storage="f3
             "launches_per_step": (acc["lvl_n"][s] + acc["lvl_first_n"][s]) / max(n_prof, 1)})
     cs = sorted(clock["samples"])
     shader_clock = ({"mean_ghz": sum(cs) / len(cs), "min_ghz": cs[0], "max_ghz": cs[-1], "samples": len(cs),
-                     "method": "one wave on a second stream during the timed region: s_memtime / s_memrealtime, 3 ms every 15 ms"}
+                     "method": "inside the iteration kernel: s_memtime / s_memrealtime over one workgroup's lifetime in the middle of "
+                               "every launch, one sample per event-bracketed step of the timed region"}
                     if cs else None)
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     ratio, src = measured_traffic(cfg)

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define ICA_ABI_VERSION 3   /* 3: ica_problem.storage, void* image pointers, ica_op_ref_* (rounds 2-3) */
+#define ICA_ABI_VERSION 4   /* 3: ica_problem.storage, void* image pointers, ica_op_ref_*; 4: ica_stats.shader_clock_ghz */
 #define ICA_MAX_PARAMS 8
 #define ICA_MAX_SCALES 16
 #define ICA_MAX_CHANNELS 4
@@ -119,6 +119,8 @@ typedef struct ica_stats {
   int64_t first_launches[ICA_MAX_SCALES];  /* same three figures for the L2 first-iteration launches    */
   double first_kernel_ms[ICA_MAX_SCALES];
   double first_kernel_bytes[ICA_MAX_SCALES];
+  double shader_clock_ghz;                 /* clock the iteration kernel ran at (profiling on): cycles / 100 MHz ticks */
+                                           /* of one workgroup's lifetime in the middle of every launch; else 0        */
 } ica_stats;
 
 typedef struct ica_ctx ica_ctx;

@@ -5,7 +5,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ICA_ABI_VERSION = 3   # include/ica_hip.h
+ICA_ABI_VERSION = 4   # include/ica_hip.h
 ICA_MAX_SCALES = 16
 ICA_TRACE_STRIDE = 10
 ICA_FLAG_EXACT_UPDATE = 1
@@ -35,7 +35,7 @@ class Stats(C.Structure):
                 ("iter_kernel_bytes", C.c_double * ICA_MAX_SCALES), ("level_width", C.c_int32 * ICA_MAX_SCALES),
                 ("level_height", C.c_int32 * ICA_MAX_SCALES),
                 ("first_launches", C.c_int64 * ICA_MAX_SCALES), ("first_kernel_ms", C.c_double * ICA_MAX_SCALES),
-                ("first_kernel_bytes", C.c_double * ICA_MAX_SCALES)]
+                ("first_kernel_bytes", C.c_double * ICA_MAX_SCALES), ("shader_clock_ghz", C.c_double)]
 
 
 _P = C.c_void_p

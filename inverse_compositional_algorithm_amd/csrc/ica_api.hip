@@ -82,7 +82,7 @@ struct ica_ctx {
   // workspaces
   DevBuf pyr1[ICA_MAX_SCALES], pyr2[ICA_MAX_SCALES];  // levels >= 1
   DevBuf tmp_resample;                                // intermediate of the separable pyramid pass
-  DevBuf partials, hinv, p_prev, lambda_it, error, niter, lists, counts, count_hist, minmax, mm_part, mm_in, out_part, clock_probe;
+  DevBuf partials, hinv, p_prev, lambda_it, error, niter, lists, counts, count_hist, minmax, mm_part, mm_in, out_part, clock_probe, clock_acc;
   DevBuf scratch_p, ref_part;
   int* pinned_count = nullptr;   // one list's shard counters for synchronous reads + a [scales][max_iter] board the kernels post to
   int* board = nullptr;          // host pointer of the board (pinned, host-coherent)
@@ -100,7 +100,7 @@ struct ica_ctx {
     if (handover) (void)hipEventDestroy(handover);
     for (int i = 0; i < ICA_MAX_SCALES; ++i) { pyr1[i].release(); pyr2[i].release(); }
     DevBuf* all[] = {&tmp_resample, &partials, &hinv, &p_prev, &lambda_it, &error, &niter, &lists, &counts,
-                     &count_hist, &minmax, &mm_part, &mm_in, &out_part, &scratch_p, &ref_part, &clock_probe};
+                     &count_hist, &minmax, &mm_part, &mm_in, &out_part, &scratch_p, &ref_part, &clock_probe, &clock_acc};
     for (auto* b : all) b->release();
     if (pinned_count) (void)hipHostFree(pinned_count);
     if (board) (void)hipHostFree(board);
@@ -739,6 +739,10 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const void* I1v, co
   int* counts = ctx->counts.as<int>();
   const int list_cap = list_shard_cap(B);                       // three sharded lists (ica_kernels.hpp)
   const size_t list_stride = (size_t)kListShards * list_cap, cnt_stride = (size_t)kListShards * kShardStride;
+  if (ctx->profiling) {   // the iteration kernel's clock accumulators (ica_common.hpp, LevelArgs::clock_acc)
+    ICA_HIP(ctx, ctx->clock_acc.ensure(4 * sizeof(unsigned long long)));
+    ICA_HIP(ctx, hipMemsetAsync(ctx->clock_acc.ptr, 0, 4 * sizeof(unsigned long long), st));
+  }
   struct EvRec { int level; size_t e0, e1; bool first; };
   std::vector<EvRec> evrecs;
   size_t ev_used = 0;
@@ -771,6 +775,7 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const void* I1v, co
     la.p = p; la.lambda_it = ctx->lambda_it.as<double>(); la.minmax = mm2 + (size_t)s * B * 2;
     la.partials = ctx->partials.as<double>();
     la.n_pairs = B;
+    la.clock_acc = ctx->profiling ? ctx->clock_acc.as<unsigned long long>() : nullptr;
 
     // L2 (ref :96-103): the steepest-descent Hessian does not depend on p and is needed once per level.  Instead of a
     // separate pass over I1, iteration 0 runs the kernel variant that accumulates H next to b (weights identically 1)
@@ -878,6 +883,11 @@ int ica_solve_batch_dev(ica_ctx* ctx, const ica_problem* pr, const void* I1v, co
       float ms = 0.f;
       ICA_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[r.e0], ctx->ev_pool[r.e1]));
       (r.first ? stats->first_kernel_ms : stats->iter_kernel_ms)[r.level] += ms;
+    }
+    if (ctx->profiling) {
+      unsigned long long acc[2] = {0, 0};
+      ICA_HIP(ctx, hipMemcpy(acc, ctx->clock_acc.ptr, sizeof(acc), hipMemcpyDeviceToHost));
+      stats->shader_clock_ghz = acc[1] ? (double)acc[0] / ((double)acc[1] * 10.0) : 0.0;   // cycles per 10 ns tick
     }
   }
   return ICA_OK;

@@ -64,6 +64,8 @@ struct LevelArgs {
   int n_pairs;              // pairs covered by this launch (the bound when act_list == nullptr; picks the block map)
   int* host_slot;           // nullable, host-visible: receives *act_count (pairs entering this iteration)
   double* partials;         // [slot][tiles][kAccStride]; slot = index into the active list (= pair without a list)
+  unsigned long long* clock_acc;  // nullable (profiling): [0] += shader cycles, [1] += 100 MHz ticks of one wave's lifetime in the
+                                  // middle of this launch, [2..3] its start stamps (the shader clock THIS kernel runs at)
 };
 
 // ---- active-pair lists ------------------------------------------------------------------------------

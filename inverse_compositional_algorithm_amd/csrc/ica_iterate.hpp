@@ -359,6 +359,14 @@ __global__ __launch_bounds__((IterCfg<C, U8>::block), (IterCfg<C, U8>::loader ? 
   long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const long long stamp_begin = clock64(), stamp_rt_begin = wall_clock64();
 #endif
+  // Profiling: the workgroup in the middle of the grid notes when it starts (in memory: no register lives across the
+  // kernel for it) and, at the end, adds its lifetime in shader cycles and in ticks of the constant 100 MHz counter to
+  // the context's accumulators -- the clock the chip sustains under THIS kernel, measured without a second stream.
+  const bool clock_wg = a.clock_acc != nullptr && blockIdx.x == (gridDim.x >> 1);
+  if (clock_wg && threadIdx.x == 0) {
+    a.clock_acc[2] = (unsigned long long)clock64();
+    a.clock_acc[3] = (unsigned long long)wall_clock64();
+  }
   const int tx = tile_id % a.tiles_x, ty = tile_id / a.tiles_x;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1455,6 +1463,10 @@ __global__ __launch_bounds__((IterCfg<C, U8>::block), (IterCfg<C, U8>::loader ? 
       }
     }
     if (kFoldSplit && part == 0) __syncthreads();
+  }
+  if (clock_wg && threadIdx.x == 0) {
+    a.clock_acc[0] += (unsigned long long)clock64() - a.clock_acc[2];
+    a.clock_acc[1] += (unsigned long long)wall_clock64() - a.clock_acc[3];
   }
 #ifdef ICA_STAMP
   {

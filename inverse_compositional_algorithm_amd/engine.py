@@ -142,6 +142,7 @@ class IcaEngine:
                              first_launches=list(st.first_launches[:ns]),
                              first_kernel_ms=list(st.first_kernel_ms[:ns]),
                              first_kernel_bytes=list(st.first_kernel_bytes[:ns]),
+                             shader_clock_ghz=float(st.shader_clock_ghz),
                              level_size=[(st.level_width[s], st.level_height[s]) for s in range(ns)])
         return res
 

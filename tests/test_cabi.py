@@ -35,12 +35,13 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 def test_struct_layout_matches_header(lib):
     from inverse_compositional_algorithm_amd._lib import Problem, Stats
     assert C.sizeof(Problem) == 12 * 4 + 6 * 8
-    assert C.sizeof(Stats) == 16 * 8 + 8 + 16 * 8 + 16 * 8 + 16 * 8 + 2 * 16 * 4 + 3 * 16 * 8
+    assert C.sizeof(Stats) == 16 * 8 + 8 + 16 * 8 + 16 * 8 + 16 * 8 + 2 * 16 * 4 + 3 * 16 * 8 + 8
+    assert Stats.shader_clock_ghz.offset == C.sizeof(Stats) - 8
     assert Problem.tol.offset == 48 and Problem.lambda_ratio.offset == 88
 
 
 def test_host_only_entry_points(lib):
-    assert lib.ica_version() == 3
+    assert lib.ica_version() == 4
     assert [lib.ica_nparams(t) for t in (1, 2, 3, 4, 5)] == [2, 3, 4, 6, 8]  # transformation.py:16-32
     assert lib.ica_nparams(0) < 0 and lib.ica_nparams(6) < 0
     w, h = C.c_int(), C.c_int()
