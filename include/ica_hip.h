@@ -138,7 +138,10 @@ int ica_set_profiling(ica_ctx* ctx, int on);       /* HIP events around every it
 /* Measurement aid (no reference counterpart): ONE wave on this ctx's stream compares the shader clock counter
  * (s_memtime) with the constant 100 MHz counter (s_memrealtime) for `duration_us` microseconds and returns the
  * shader clock it saw, in GHz.  Run on a second ctx / stream while another ctx computes, it reports the clock the
- * chip sustains UNDER THAT LOAD (the driver's sysfs reading does not track it).  Blocks until the wave is done. */
+ * chip sustains UNDER THAT LOAD (the driver's sysfs reading does not track it).  Blocks until the wave is done.
+ * Caution: two HIP streams may share a hardware queue, in which case the probe runs BETWEEN the other context's
+ * kernels, delays them and reads the idle clock; ica_stats.shader_clock_ghz (measured inside the iteration kernel,
+ * profiling on) has neither problem and is what bench.py reports. */
 int ica_op_shader_clock_dev(ica_ctx* ctx, int duration_us, double* ghz_out);
 int ica_nparams(int transform_type);   /* transformation.py:16-32; < 0 if unknown                    */
 /* zoom.py:8-22: level sizes, int(np.round(n*nu)) (round-half-even). */
