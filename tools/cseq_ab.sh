@@ -8,8 +8,8 @@ echo "== gpu tests default" && timeout -k 10 500 python -m pytest tests -m gpu -
 echo "== C=3 robust homography 1080x1920" && tools/variant_times.sh "default cseq" --reps 5 --size 1080 1920 --channels 3 --transform 5 --robust 3 --batch 256 | tee $O/vt_c3_rob.txt
 echo "== C=3 L2 homography 1080x1920" && tools/variant_times.sh "default cseq" --reps 5 --size 1080 1920 --channels 3 --transform 5 --robust 0 --batch 256 | tee $O/vt_c3_l2.txt
 echo "== C=3 L2 affinity 512" && tools/variant_times.sh "default cseq" --reps 5 --size 512 512 --channels 3 --transform 4 --robust 0 --batch 1024 | tee $O/vt_c3_aff.txt
-unset ICA_LIB
-echo "== traffic C=3 default" && timeout -k 10 300 tools/pmc_traffic.sh r3g_c3 --size 1080 1920 --channels 3 --transform 5 --robust 3 --batch 256 | tee $O/traffic_c3.txt
-echo "== bench cfg5" && timeout -k 10 400 python bench.py --config 5 --steps 2 --warmup 1 --no-per-config --no-cpu-baseline > $O/bench_cfg5.json 2> $O/bench_cfg5.err; tail -c 1500 $O/bench_cfg5.json
-export ICA_LIB=$R/tools/abl/lib_cseq.so
-echo "== bench cfg5 cseq" && timeout -k 10 400 python bench.py --config 5 --steps 2 --warmup 1 --no-per-config --no-cpu-baseline > $O/bench_cfg5_old.json 2> $O/bench_cfg5_old.err; tail -c 1500 $O/bench_cfg5_old.json
+for v in default cseq; do
+  if [ "$v" = default ]; then unset ICA_LIB; else export ICA_LIB=$R/tools/abl/lib_$v.so; fi
+  echo "== traffic C=3 $v" && timeout -k 10 300 tools/pmc_traffic.sh cseq_ab_$v --size 1080 1920 --channels 3 --transform 5 --robust 3 --batch 256 | tee $O/traffic_c3_$v.txt
+  echo "== bench cfg5 $v" && timeout -k 10 400 python bench.py --config 5 --steps 2 --warmup 1 --no-per-config --no-cpu-baseline > $O/bench_cfg5_$v.json 2> $O/bench_cfg5_$v.err; tail -c 1500 $O/bench_cfg5_$v.json
+done
