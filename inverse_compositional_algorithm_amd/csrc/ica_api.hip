@@ -3,6 +3,7 @@
 // ica_kernels.hpp on the context's stream; there is no CPU compute path.
 #include <hip/hip_runtime.h>
 
+#include <climits>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -46,7 +47,8 @@ struct DevBuf {
 };
 
 struct DeviceBandOp {
-  DevBuf start, wT, vj0, vspan, vown0, vown1, vw, vwslot, hc0;
+  DevBuf start, wT, vj0, vspan, vown0, vown1, vw, vwslot, hc0, wpair, hoff;
+  bool pair_pass = false;  // the adjacent-output horizontal pass applies (ica_kernels.hpp, FusedCols)
   int n_in = 0, n_out = 0, K = 0;
   int hnb = 0, hblocks = 0;  // fused step, this operator on the x axis: outputs per column block (0: not usable), blocks
   int vspan_max = 0;   // widest input span of kOutsV consecutive outputs (window of the vertical pass)
@@ -56,8 +58,10 @@ struct DeviceBandOp {
     return BandOp{start.as<int>(), wT.as<float>(), vj0.as<int>(), vspan.as<int>(), vown0.as<int>(), vown1.as<int>(),
                   vw.as<float>(), vwslot.as<int>(), n_in, n_out, K};
   }
-  FusedCols cols() const { return FusedCols{hc0.as<int>(), hnb}; }
-  void release() { start.release(); wT.release(); vj0.release(); vspan.release(); vown0.release(); vown1.release(); vw.release(); vwslot.release(); hc0.release(); }
+  FusedCols cols() const {
+    return FusedCols{hc0.as<int>(), hnb, pair_pass ? wpair.as<float>() : nullptr, pair_pass ? hoff.as<int>() : nullptr};
+  }
+  void release() { start.release(); wT.release(); vj0.release(); vspan.release(); vown0.release(); vown1.release(); vw.release(); vwslot.release(); hc0.release(); wpair.release(); hoff.release(); }
 };
 
 struct LevelGeom {
@@ -266,6 +270,45 @@ int get_op(ica_ctx* ctx, int n_in, int n_out, DeviceBandOp** out) {
       for (int ob = 0; ob < n_out; ob += nb) hc0.push_back(h.start[ob] & ~3);
     }
   }
+  // Adjacent-output horizontal pass: does every pair of outputs (ob + 2l, ob + 2l + 1) of every column block have its
+  // two bands (the nonzero weights) inside the kPairWin columns that start 4 l columns after a common, 4-aligned origin
+  // at most 3 groups before / 1 group after the block's first column?  True for a decimation by exactly 2 (band of 26,
+  // starts 2 o - 12), image borders included: there the stored band is longer than the nonzero weights.
+  std::vector<float> wpair;
+  std::vector<int> hoff;
+  if (d->hnb > 0 && d->hnb % 2 == 0 && !getenv("ICA_NO_PAIR_PASS")) {
+    const int nb = d->hnb, nbk = d->hblocks;
+    std::vector<int> f0(n_out), f1(n_out);   // first / last column with a nonzero weight
+    for (int o = 0; o < n_out; ++o) {
+      int a = h.K, b = -1;
+      for (int k = 0; k < h.K; ++k)
+        if (h.w[(size_t)o * h.K + k] != 0.0) { a = std::min(a, k); b = std::max(b, k); }
+      if (b < 0) { a = 0; b = 0; }
+      f0[o] = h.start[o] + a;
+      f1[o] = h.start[o] + b;
+    }
+    bool ok = true;
+    wpair.assign((size_t)nbk * kPairWin * 64 * 2, 0.0f);
+    hoff.assign(nbk, 0);
+    for (int bx = 0; bx < nbk && ok; ++bx) {
+      const int ob = bx * nb, oe = std::min(ob + nb, n_out), c0 = hc0[bx];
+      int org = INT_MAX;
+      for (int o = ob; o < oe; ++o) org = std::min(org, f0[o] - 4 * ((o - ob) / 2));
+      org = (int)std::floor(org / 4.0) * 4;
+      const int off = (org - c0) / 4;
+      if ((org - c0) % 4 != 0 || off < -3 || off > 1) { ok = false; break; }
+      hoff[bx] = off;
+      for (int o = ob; o < oe && ok; ++o) {
+        const int l = (o - ob) / 2, q = (o - ob) & 1, w0 = org + 4 * l;
+        if (f0[o] < w0 || f1[o] > w0 + kPairWin - 1) { ok = false; break; }
+        for (int k = 0; k < h.K; ++k) {
+          const int j = h.start[o] + k - w0;
+          if (j >= 0 && j < kPairWin) wpair[(((size_t)bx * kPairWin + j) * 64 + l) * 2 + q] = (float)h.w[(size_t)o * h.K + k];
+        }
+      }
+    }
+    d->pair_pass = ok;
+  }
   auto up = [&](DevBuf& b, const void* src, size_t bytes) -> hipError_t {
     hipError_t e = b.ensure(bytes);
     if (e == hipSuccess) e = hipMemcpy(b.ptr, src, bytes, hipMemcpyHostToDevice);
@@ -280,6 +323,8 @@ int get_op(ica_ctx* ctx, int n_in, int n_out, DeviceBandOp** out) {
   if (e == hipSuccess) e = up(d->vw, vw.data(), vw.size() * sizeof(float));
   if (e == hipSuccess) e = up(d->vwslot, vwslot.data(), vwslot.size() * sizeof(int));
   if (e == hipSuccess && !hc0.empty()) e = up(d->hc0, hc0.data(), hc0.size() * sizeof(int));
+  if (e == hipSuccess && d->pair_pass) e = up(d->wpair, wpair.data(), wpair.size() * sizeof(float));
+  if (e == hipSuccess && d->pair_pass) e = up(d->hoff, hoff.data(), hoff.size() * sizeof(int));
   if (e != hipSuccess) {
     ctx->last_error = std::string("pyramid operator upload: ") + hipGetErrorString(e);
     d->release();
@@ -340,9 +385,14 @@ int launch_pyramid_down(ica_ctx* ctx, int batch, int C, int H, int W, int h, int
     for (int p0 = 0; p0 < planes; p0 += step) {
       const int np = std::min(step, planes - p0);
       const size_t po = (size_t)p0 * vgroups * xb * 2;
-      hipLaunchKernelGGL((ica_resample_fused_kernel<TIn>), dim3(xb, (vgroups + kWaves - 1) / kWaves, np), dim3(kBlock), 0,
-                         ctx->stream, in + (size_t)p0 * H * W, out + (size_t)p0 * h * w, W, oy->view(), ox->view(),
-                         ox->cols(), part ? part + po : nullptr, opart + po);
+      if (ox->pair_pass)
+        hipLaunchKernelGGL((ica_resample_fused_kernel<TIn, true>), dim3(xb, (vgroups + kWaves - 1) / kWaves, np), dim3(kBlock), 0,
+                           ctx->stream, in + (size_t)p0 * H * W, out + (size_t)p0 * h * w, W, oy->view(), ox->view(),
+                           ox->cols(), part ? part + po : nullptr, opart + po);
+      else
+        hipLaunchKernelGGL((ica_resample_fused_kernel<TIn, false>), dim3(xb, (vgroups + kWaves - 1) / kWaves, np), dim3(kBlock), 0,
+                           ctx->stream, in + (size_t)p0 * H * W, out + (size_t)p0 * h * w, W, oy->view(), ox->view(),
+                           ox->cols(), part ? part + po : nullptr, opart + po);
     }
     if (part)
       hipLaunchKernelGGL(ica_minmax_final_kernel, dim3((batch + kWaves - 1) / kWaves), dim3(kBlock), 0, ctx->stream, part,

@@ -859,18 +859,32 @@ constexpr int kFusedW = 256;     // input columns per column block
 #endif
 constexpr int kFusedHalf = ICA_FUSED_HALF;    // rows per horizontal half pass (LDS: 8 x 256 floats per wave)
 
+constexpr int kPairWin = 28;      // input columns a lane reads for its two adjacent outputs (7 aligned groups of 4)
 struct FusedCols {
   const int* c0;   // [blocks] first input column of each block (multiple of 4)
   int nb;          // output columns per block (<= 128: two per lane)
+  // Adjacent-output horizontal pass (nullptr: the operator is not regular enough for it, see get_op): lane l of block b
+  // produces outputs b * nb + 2l and + 2l + 1 from the kPairWin columns that start at c0[b] + 4 * (l + hoff[b]);
+  // wpair[((b * kPairWin + j) * 64 + l) * 2 + q] = weight of window column j for output q of the pair (0 outside its band)
+  const float* wpair;
+  const int* hoff; // [blocks] window origin of lane 0 relative to c0, in groups of 4 columns (-3 .. 1)
 };
 
-template <class TIn>
-__global__ __launch_bounds__(kBlock) void ica_resample_fused_kernel(const TIn* __restrict__ in, float* __restrict__ out,
+// PAIR: the horizontal operator is applied by the adjacent-output pass (FusedCols::wpair), else by the generic one -- two
+// instantiations, because one kernel holding both paid for the larger of the two in registers (measured: 4.5 instead of
+// 2.1 ms for the generic pass of the 1024^2 level).
+#ifndef ICA_PAIR_WAVES   // waves per SIMD the register allocator leaves room for in the adjacent-output instantiation (119
+                         // registers unconstrained; forced to 96 for a fifth wave it spills 20 bytes and is 1-4 % slower)
+#define ICA_PAIR_WAVES 4
+#endif
+template <class TIn, bool PAIR>
+__global__ __launch_bounds__(kBlock, (PAIR ? ICA_PAIR_WAVES : 1)) void ica_resample_fused_kernel(const TIn* __restrict__ in, float* __restrict__ out,
                                                                     int W, BandOp oy, BandOp ox, FusedCols fc,
                                                                     float* __restrict__ mm_part, float* __restrict__ out_part) {
   typedef float vec4f __attribute__((ext_vector_type(4)));
   typedef float vec2f __attribute__((ext_vector_type(2)));
-  __shared__ __attribute__((aligned(16))) float tiles[kWaves][kFusedHalf][kFusedW];
+  constexpr int kTileFloats = kFusedHalf * kFusedW;   // a wave-private tile: kFusedHalf rows x kFusedW columns
+  __shared__ __attribute__((aligned(16))) float tiles[kWaves * kTileFloats];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = blockIdx.y * kWaves + wave;
@@ -891,7 +905,7 @@ __global__ __launch_bounds__(kBlock) void ica_resample_fused_kernel(const TIn* _
   const bool xin = x < W;  // (W % 4 == 0: a lane's four columns are in or out together)
   const TIn* col = in + (size_t)pl * oy.n_in * W + (size_t)j0 * W + (xin ? x : 0);
   float lo = INFINITY, hi = -INFINITY;
-  float (*tile)[kFusedW] = tiles[wave];
+  float* const tile = tiles + wave * kTileFloats;   // tile[i * kFusedW + c]
   // (Built and measured instead of the plain loads below: the rows through a ring of 8 LDS-DMA slots in the wave's idle
   //  tile, 8 KB in flight per wave and no registers spent.  Next to the DMA intrinsic the compiler no longer keeps the
   //  wave-uniform weights on the scalar path, and with hand-written s_load + wait per row the scalar-cache misses of
@@ -944,14 +958,94 @@ __global__ __launch_bounds__(kBlock) void ica_resample_fused_kernel(const TIn* _
   float olo = INFINITY, ohi = -INFINITY;
 #pragma unroll
   for (int hh = 0; hh < kOutsV / kFusedHalf; ++hh) {
+    if constexpr (PAIR) {
+      // Adjacent-output pass (regular operators: decimation by 2).  A lane produces outputs ob + 2 lane and ob + 2 lane + 1,
+      // whose bands lie inside the same 28 consecutive columns: the rows go to LDS as they are (one ds_write_b128 per
+      // lane and row) and come back as 7 aligned ds_read_b128 per lane and row -- 28 tile values for 2 x 26 taps, where
+      // one output per read needs 52 ds_read_b32 (the LDS reads were what bounded the pyramid step).  Per-lane weights
+      // on the window's columns (zero outside an output's band), so image borders need nothing special; the terms of
+      // an output are added in the same order as in the generic pass below (ascending column, zero-weight terms change
+      // nothing): bit-identical results.
+#pragma unroll
+      for (int i = 0; i < kFusedHalf; ++i) {
+        vec4f v4;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) v4[v] = acc[hh * kFusedHalf + i][v];
+        *reinterpret_cast<vec4f*>(&tile[i * kFusedW + 4 * lane]) = v4;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int o = ob + 2 * lane;
+      const float* wp = fc.wpair + ((size_t)blockIdx.x * kPairWin * 64 + lane) * 2;
+      // group m of the lane's window sits at group lane + hoff + m of a tile row.  Groups before the row's first or
+      // after its last one (block 0's left edge, the masked lanes at the right) carry zero weights: any finite value
+      // does for them, so the group index is clamped into the row instead of padding the tile (the 32 KB of four
+      // tiles are what lets five workgroups share a CU).
+      const int g0 = lane + fc.hoff[blockIdx.x];
+      float aA[kFusedHalf], aB[kFusedHalf];
+#pragma unroll
+      for (int i = 0; i < kFusedHalf; ++i) { aA[i] = 0.f; aB[i] = 0.f; }
+      vec2f wcur[4], wnxt[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) wcur[t] = *reinterpret_cast<const vec2f*>(wp + (size_t)t * 128);
+#pragma unroll
+      for (int m = 0; m < kPairWin / 4; ++m) {
+        if (m + 1 < kPairWin / 4) {   // the next group's weights (per-lane global loads, L1 / L2 hits) under this group's arithmetic
+#pragma unroll
+          for (int t = 0; t < 4; ++t) wnxt[t] = *reinterpret_cast<const vec2f*>(wp + (size_t)(4 * (m + 1) + t) * 128);
+        }
+        const float* tq = tile + 4 * min(max(g0 + m, 0), kFusedW / 4 - 1);
+#pragma unroll
+        for (int i = 0; i < kFusedHalf; ++i) {
+          const vec4f v4 = *reinterpret_cast<const vec4f*>(tq + i * kFusedW);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            aA[i] = fmaf(wcur[t][0], v4[t], aA[i]);
+            aB[i] = fmaf(wcur[t][1], v4[t], aB[i]);
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) wcur[t] = wnxt[t];
+        // (the sums are formed HERE: left alone, the optimiser sinks every multiply-add to the stores below and keeps all
+        //  56 tile reads -- 224 registers -- alive until then)
+#pragma unroll
+        for (int i = 0; i < kFusedHalf; ++i) asm volatile("" : "+v"(aA[i]), "+v"(aB[i]));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int i = 0; i < kFusedHalf; ++i) {
+        const int r = hh * kFusedHalf + i;
+        if (r < no) {
+          float* dst = out + ((size_t)pl * oy.n_out + o0 + r) * ox.n_out + o;
+          if (o + 1 < oe) {
+            if ((ox.n_out & 1) == 0) {
+              vec2f st; st[0] = aA[i]; st[1] = aB[i];
+              *reinterpret_cast<vec2f*>(dst) = st;   // (even row pitch and even o: 8-byte aligned)
+            } else {
+              dst[0] = aA[i]; dst[1] = aB[i];
+            }
+            olo = fminf(olo, fminf(aA[i], aB[i]));
+            ohi = fmaxf(ohi, fmaxf(aA[i], aB[i]));
+          } else if (o < oe) {
+            dst[0] = aA[i];
+            olo = fminf(olo, aA[i]);
+            ohi = fmaxf(ohi, aA[i]);
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();  // everyone has read this half before the next one overwrites it
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
     // relative column c = 4 * lane + v goes to plane (c & 1), slot (c >> 1): evens at [0, 128), odds at [128, 256)
 #pragma unroll
     for (int i = 0; i < kFusedHalf; ++i) {
       vec2f ev, od;
       ev[0] = acc[hh * kFusedHalf + i][0]; ev[1] = acc[hh * kFusedHalf + i][2];
       od[0] = acc[hh * kFusedHalf + i][1]; od[1] = acc[hh * kFusedHalf + i][3];
-      *reinterpret_cast<vec2f*>(&tile[i][2 * lane]) = ev;
-      *reinterpret_cast<vec2f*>(&tile[i][kFusedW / 2 + 2 * lane]) = od;
+      *reinterpret_cast<vec2f*>(&tile[i * kFusedW + 2 * lane]) = ev;
+      *reinterpret_cast<vec2f*>(&tile[i * kFusedW + kFusedW / 2 + 2 * lane]) = od;
     }
     // the tile is this wave's own and a wave's LDS operations execute in order: only the compiler has to be told
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -977,7 +1071,7 @@ __global__ __launch_bounds__(kBlock) void ica_resample_fused_kernel(const TIn* _
         for (int kk = 0; kk < 16; ++kk) {
           if (k0 + kk < ox.K) {  // wave-uniform
             const int c = s + k0 + kk;
-            const float* q = &tile[0][(c & 1) * (kFusedW / 2) + (c >> 1)];
+            const float* q = &tile[(c & 1) * (kFusedW / 2) + (c >> 1)];
 #pragma unroll
             for (int i = 0; i < kFusedHalf; ++i) a8[i] = fmaf(wk[kk], q[i * kFusedW], a8[i]);
           }
@@ -998,6 +1092,7 @@ __global__ __launch_bounds__(kBlock) void ica_resample_fused_kernel(const TIn* _
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();  // everyone has read this half before the next one overwrites it
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
