@@ -47,7 +47,8 @@ struct DevBuf {
 };
 
 struct DeviceBandOp {
-  DevBuf start, wT, vj0, vspan, vown0, vown1, vw, vwslot, hc0, wpair, hoff;
+  DevBuf start, wT, vj0, vspan, vown0, vown1, vw, vwslot, hc0, wpair, hoff, sw;
+  int vfast_slot = -1;     // window slot of the groups made of shift-invariant outputs only (BandOp::vfast_slot)
   bool pair_pass = false;  // the adjacent-output horizontal pass applies (ica_kernels.hpp, FusedCols)
   int n_in = 0, n_out = 0, K = 0;
   int hnb = 0, hblocks = 0;  // fused step, this operator on the x axis: outputs per column block (0: not usable), blocks
@@ -56,12 +57,12 @@ struct DeviceBandOp {
   bool vcover = false; // the groups' "own" ranges cover the whole input axis (min/max can be folded into the pass)
   BandOp view() const {
     return BandOp{start.as<int>(), wT.as<float>(), vj0.as<int>(), vspan.as<int>(), vown0.as<int>(), vown1.as<int>(),
-                  vw.as<float>(), vwslot.as<int>(), n_in, n_out, K};
+                  vw.as<float>(), vwslot.as<int>(), n_in, n_out, K, sw.as<float>(), vfast_slot};
   }
   FusedCols cols() const {
     return FusedCols{hc0.as<int>(), hnb, pair_pass ? wpair.as<float>() : nullptr, pair_pass ? hoff.as<int>() : nullptr};
   }
-  void release() { start.release(); wT.release(); vj0.release(); vspan.release(); vown0.release(); vown1.release(); vw.release(); vwslot.release(); hc0.release(); wpair.release(); hoff.release(); }
+  void release() { start.release(); wT.release(); vj0.release(); vspan.release(); vown0.release(); vown1.release(); vw.release(); vwslot.release(); hc0.release(); wpair.release(); hoff.release(); sw.release(); }
 };
 
 struct LevelGeom {
@@ -195,6 +196,28 @@ int get_op(ica_ctx* ctx, int n_in, int n_out, DeviceBandOp** out) {
     return ICA_OK;
   }
   HostBandOp h = build_rescale_op(n_in, n_out);
+  // Away from the border a decimation by exactly 2 is shift-invariant; the float64 recursions that build the operator
+  // leave the interior rows equal to the last bit or two.  Make them bit-identical (every pyramid kernel then applies the
+  // same weights to the same samples in the same order) and remember the range.
+  int inv_first = 0, inv_end = 0;   // outputs [inv_first, inv_end)
+  std::vector<float> sw(kFastK, 0.0f);
+  if (n_in == 2 * n_out && h.K == kFastK && n_out >= 4 * kOutsV) {
+    const int mid = n_out / 2;
+    auto same = [&](int o) {
+      if (h.start[o] - h.start[mid] != 2 * (o - mid)) return false;
+      for (int k = 0; k < h.K; ++k)
+        if (std::fabs((float)h.w[(size_t)o * h.K + k] - (float)h.w[(size_t)mid * h.K + k]) > 1.2e-7f) return false;
+      return true;
+    };
+    int a = mid, b = mid;
+    while (a > 0 && same(a - 1)) --a;
+    while (b + 1 < n_out && same(b + 1)) ++b;
+    inv_first = a;
+    inv_end = b + 1;
+    for (int o = inv_first; o < inv_end; ++o)
+      for (int k = 0; k < h.K; ++k) h.w[(size_t)o * h.K + k] = h.w[(size_t)mid * h.K + k];
+    for (int k = 0; k < h.K; ++k) sw[k] = (float)h.w[(size_t)mid * h.K + k];
+  }
   std::vector<float> wT((size_t)h.K * n_out);
   for (int o = 0; o < n_out; ++o)
     for (int k = 0; k < h.K; ++k) wT[(size_t)k * n_out + o] = (float)h.w[(size_t)o * h.K + k];
@@ -235,6 +258,17 @@ int get_op(ica_ctx* ctx, int n_in, int n_out, DeviceBandOp** out) {
     vwslot[g] = slot;
   }
   if (vw.empty()) vw.assign(win.size(), 0.0f);
+  {  // the window slot of a group that lies inside the shift-invariant range (all such groups share one slot)
+    const int gf = (inv_first + kOutsV - 1) / kOutsV, ge = inv_end / kOutsV;
+    if (ge > gf) {
+      d->vfast_slot = vwslot[gf];
+      for (int g = gf; g < ge; ++g)
+        if (vwslot[g] != d->vfast_slot) d->vfast_slot = -1;
+      // a border group must not share that slot (its outputs are not all shift-invariant)
+      for (int g = 0; g < groups && d->vfast_slot >= 0; ++g)
+        if ((g < gf || g >= ge) && vwslot[g] == d->vfast_slot) d->vfast_slot = -1;
+    }
+  }
   if (getenv("ICA_DEBUG_OPS"))
     fprintf(stderr, "ica: rescale operator %d -> %d: K %d, %d groups of %d outputs, %d distinct weight windows\n", n_in, n_out,
             h.K, groups, kOutsV, (int)(vw.size() / win.size()));
@@ -315,6 +349,7 @@ int get_op(ica_ctx* ctx, int n_in, int n_out, DeviceBandOp** out) {
     return e;
   };
   hipError_t e = up(d->start, h.start.data(), h.start.size() * sizeof(int));
+  if (e == hipSuccess) e = up(d->sw, sw.data(), sw.size() * sizeof(float));
   if (e == hipSuccess) e = up(d->wT, wT.data(), wT.size() * sizeof(float));
   if (e == hipSuccess) e = up(d->vj0, vj0.data(), vj0.size() * sizeof(int));
   if (e == hipSuccess) e = up(d->vspan, vspan.data(), vspan.size() * sizeof(int));

@@ -636,7 +636,20 @@ struct BandOp {
                        // border a decimation by an integer factor is shift-invariant, the whole table is then a few KB
                        // and the weight fetches (scalar loads, one row of weights per input row) stay in the scalar cache
   int n_in, n_out, K;
+  // Decimation by exactly 2: away from the border every output has the same kFastK weights, `sw` (made bit-identical on the
+  // host), and the groups whose window is slot `vfast_slot` consist of such outputs only (-1: none)
+  const float* sw;
+  int vfast_slot;
 };
+constexpr int kFastK = 26;   // taps of the factor-2 operator (Gaussian 0.5 + B-spline prefilter + zoom)
+template <int J> using IC_ = std::integral_constant<int, J>;
+template <int J0, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {   // f(IC_<J0>{}), f(IC_<J0 + 1>{}), ... N calls, indices compile-time
+  if constexpr (N > 0) {
+    f(IC_<J0>{});
+    static_for<J0 + 1, N - 1>(f);
+  }
+}
 
 #ifndef ICA_OUTSV
 #define ICA_OUTSV 16
@@ -944,6 +957,53 @@ __global__ __launch_bounds__(kBlock, (PAIR ? ICA_PAIR_WAVES : 1)) void ica_resam
       }
     }
   };
+  // Interior groups of a decimation by 2: output i of the group takes rows 2 i .. 2 i + 25 of the window with the same 26
+  // weights, so row jj only reaches the outputs (jj - 25) / 2 .. jj / 2 -- 26 x 16 multiply-adds per column instead of the
+  // 56 x 16 of the zero-padded window (the vertical pass's multiply-adds, on scalar weights, were two thirds of this
+  // kernel's vector time).  Every index is compile-time; the terms of an output are added in the same order.
+  constexpr int kFastSpan = 2 * (kOutsV - 1) + kFastK;
+  bool fast = false;
+  if constexpr (PAIR) fast = oy.vfast_slot >= 0 && oy.vwslot[g] == oy.vfast_slot && span == kFastSpan && no == kOutsV;
+  if (fast) {
+    if (xin) {
+      float wv[kFastK];   // wave-uniform (scalar registers)
+#pragma unroll
+      for (int k = 0; k < kFastK; ++k)
+        wv[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, oy.sw[k])));
+      typedef std::conditional_t<std::is_same_v<TIn, float>, vec4f, unsigned> row_t;
+      constexpr int kAhead = 4;   // rows of loads in flight (a queue in registers with compile-time slots)
+      row_t queue[kAhead];
+#pragma unroll
+      for (int q = 0; q < kAhead; ++q) queue[q] = *reinterpret_cast<const row_t*>(col + (size_t)q * W);
+      static_for<0, kFastSpan>([&](auto jj_c) {
+        constexpr int jj = decltype(jj_c)::value;
+        const row_t raw = queue[jj % kAhead];
+        if constexpr (jj + kAhead < kFastSpan) queue[jj % kAhead] = *reinterpret_cast<const row_t*>(col + (size_t)(jj + kAhead) * W);
+        float val[4];
+        if constexpr (std::is_same_v<TIn, float>) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) val[v] = raw[v];
+        } else {
+          val[0] = (float)(raw & 0xffu); val[1] = (float)((raw >> 8) & 0xffu); val[2] = (float)((raw >> 16) & 0xffu); val[3] = (float)(raw >> 24);
+        }
+        if (jj >= own0 && jj < own1) {   // wave-uniform
+#pragma unroll
+          for (int v = 0; v < 4; ++v) { lo = fminf(lo, val[v]); hi = fmaxf(hi, val[v]); }
+        }
+        constexpr int ilo = jj > kFastK - 1 ? (jj - (kFastK - 1) + 1) / 2 : 0;
+        constexpr int ihi = jj / 2 < kOutsV - 1 ? jj / 2 : kOutsV - 1;
+#pragma unroll
+        for (int i = ilo; i <= ihi; ++i) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) acc[i][v] = fmaf(wv[jj - 2 * i], val[v], acc[i][v]);
+          // (the sums are formed HERE, as the row arrives: the optimiser would sink them to where an output completes
+          //  and keep 26 input rows in registers instead)
+          asm volatile("" : "+v"(acc[i][0]), "+v"(acc[i][1]), "+v"(acc[i][2]), "+v"(acc[i][3]));
+        }
+        __builtin_amdgcn_sched_barrier(0);   // (keeps the queue at kAhead rows)
+      });
+    }
+  } else
   if (xin) {  // (columns past the image stay zero: the horizontal weights that reach them are zero as well)
     run(0, own0, std::false_type{});
     run(own0, own1, std::true_type{});
