@@ -196,28 +196,10 @@ int get_op(ica_ctx* ctx, int n_in, int n_out, DeviceBandOp** out) {
     return ICA_OK;
   }
   HostBandOp h = build_rescale_op(n_in, n_out);
-  // Away from the border a decimation by exactly 2 is shift-invariant; the float64 recursions that build the operator
-  // leave the interior rows equal to the last bit or two.  Make them bit-identical (every pyramid kernel then applies the
-  // same weights to the same samples in the same order) and remember the range.
+  // decimation by exactly 2: the interior outputs' weights made bit-identical (ica_pyramid.hpp)
   int inv_first = 0, inv_end = 0;   // outputs [inv_first, inv_end)
   std::vector<float> sw(kFastK, 0.0f);
-  if (n_in == 2 * n_out && h.K == kFastK && n_out >= 4 * kOutsV) {
-    const int mid = n_out / 2;
-    auto same = [&](int o) {
-      if (h.start[o] - h.start[mid] != 2 * (o - mid)) return false;
-      for (int k = 0; k < h.K; ++k)
-        if (std::fabs((float)h.w[(size_t)o * h.K + k] - (float)h.w[(size_t)mid * h.K + k]) > 1.2e-7f) return false;
-      return true;
-    };
-    int a = mid, b = mid;
-    while (a > 0 && same(a - 1)) --a;
-    while (b + 1 < n_out && same(b + 1)) ++b;
-    inv_first = a;
-    inv_end = b + 1;
-    for (int o = inv_first; o < inv_end; ++o)
-      for (int k = 0; k < h.K; ++k) h.w[(size_t)o * h.K + k] = h.w[(size_t)mid * h.K + k];
-    for (int k = 0; k < h.K; ++k) sw[k] = (float)h.w[(size_t)mid * h.K + k];
-  }
+  if (n_out >= 4 * kOutsV) canonicalise_interior(h, kFastK, inv_first, inv_end, sw);
   std::vector<float> wT((size_t)h.K * n_out);
   for (int o = 0; o < n_out; ++o)
     for (int k = 0; k < h.K; ++k) wT[(size_t)k * n_out + o] = (float)h.w[(size_t)o * h.K + k];
@@ -304,45 +286,10 @@ int get_op(ica_ctx* ctx, int n_in, int n_out, DeviceBandOp** out) {
       for (int ob = 0; ob < n_out; ob += nb) hc0.push_back(h.start[ob] & ~3);
     }
   }
-  // Adjacent-output horizontal pass: does every pair of outputs (ob + 2l, ob + 2l + 1) of every column block have its
-  // two bands (the nonzero weights) inside the kPairWin columns that start 4 l columns after a common, 4-aligned origin
-  // at most 3 groups before / 1 group after the block's first column?  True for a decimation by exactly 2 (band of 26,
-  // starts 2 o - 12), image borders included: there the stored band is longer than the nonzero weights.
+  // adjacent-output horizontal pass (ica_kernels.hpp, FusedCols): per-lane weights on a regular window, if the operator has one
   std::vector<float> wpair;
   std::vector<int> hoff;
-  if (d->hnb > 0 && d->hnb % 2 == 0 && !getenv("ICA_NO_PAIR_PASS")) {
-    const int nb = d->hnb, nbk = d->hblocks;
-    std::vector<int> f0(n_out), f1(n_out);   // first / last column with a nonzero weight
-    for (int o = 0; o < n_out; ++o) {
-      int a = h.K, b = -1;
-      for (int k = 0; k < h.K; ++k)
-        if (h.w[(size_t)o * h.K + k] != 0.0) { a = std::min(a, k); b = std::max(b, k); }
-      if (b < 0) { a = 0; b = 0; }
-      f0[o] = h.start[o] + a;
-      f1[o] = h.start[o] + b;
-    }
-    bool ok = true;
-    wpair.assign((size_t)nbk * kPairWin * 64 * 2, 0.0f);
-    hoff.assign(nbk, 0);
-    for (int bx = 0; bx < nbk && ok; ++bx) {
-      const int ob = bx * nb, oe = std::min(ob + nb, n_out), c0 = hc0[bx];
-      int org = INT_MAX;
-      for (int o = ob; o < oe; ++o) org = std::min(org, f0[o] - 4 * ((o - ob) / 2));
-      org = (int)std::floor(org / 4.0) * 4;
-      const int off = (org - c0) / 4;
-      if ((org - c0) % 4 != 0 || off < -3 || off > 1) { ok = false; break; }
-      hoff[bx] = off;
-      for (int o = ob; o < oe && ok; ++o) {
-        const int l = (o - ob) / 2, q = (o - ob) & 1, w0 = org + 4 * l;
-        if (f0[o] < w0 || f1[o] > w0 + kPairWin - 1) { ok = false; break; }
-        for (int k = 0; k < h.K; ++k) {
-          const int j = h.start[o] + k - w0;
-          if (j >= 0 && j < kPairWin) wpair[(((size_t)bx * kPairWin + j) * 64 + l) * 2 + q] = (float)h.w[(size_t)o * h.K + k];
-        }
-      }
-    }
-    d->pair_pass = ok;
-  }
+  if (d->hnb > 0 && !getenv("ICA_NO_PAIR_PASS")) d->pair_pass = build_pair_pass(h, d->hnb, hc0, kPairWin, wpair, hoff);
   auto up = [&](DevBuf& b, const void* src, size_t bytes) -> hipError_t {
     hipError_t e = b.ensure(bytes);
     if (e == hipSuccess) e = hipMemcpy(b.ptr, src, bytes, hipMemcpyHostToDevice);

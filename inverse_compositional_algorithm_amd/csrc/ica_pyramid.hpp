@@ -131,6 +131,73 @@ inline HostBandOp build_rescale_op(int n_in, int n_out) {
   return op;
 }
 
+// Away from the border a decimation by exactly 2 is shift-invariant: output o is sum_k w[k] in[2 o - 12 + k] with the same
+// `fast_k` weights; the float64 recursions that build the operator leave those rows equal to the last bit or two.  Make
+// them bit-identical (every pyramid kernel then applies the same weights to the same samples in the same order, and a
+// kernel may keep ONE copy of them) and report the range [inv_first, inv_end) and the weights `sw`.  Nothing happens
+// (empty range) unless n_in == 2 n_out and the band has `fast_k` taps.
+inline void canonicalise_interior(HostBandOp& h, int fast_k, int& inv_first, int& inv_end, std::vector<float>& sw) {
+  inv_first = inv_end = 0;
+  sw.assign(fast_k, 0.0f);
+  if (h.n_in != 2 * h.n_out || h.K != fast_k || h.n_out < 2) return;
+  const int mid = h.n_out / 2;
+  auto same = [&](int o) {
+    if (h.start[o] - h.start[mid] != 2 * (o - mid)) return false;
+    for (int k = 0; k < h.K; ++k)
+      if (std::fabs((float)h.w[(size_t)o * h.K + k] - (float)h.w[(size_t)mid * h.K + k]) > 1.2e-7f) return false;
+    return true;
+  };
+  int a = mid, b = mid;
+  while (a > 0 && same(a - 1)) --a;
+  while (b + 1 < h.n_out && same(b + 1)) ++b;
+  inv_first = a;
+  inv_end = b + 1;
+  for (int o = inv_first; o < inv_end; ++o)
+    for (int k = 0; k < h.K; ++k) h.w[(size_t)o * h.K + k] = h.w[(size_t)mid * h.K + k];
+  for (int k = 0; k < h.K; ++k) sw[k] = (float)h.w[(size_t)mid * h.K + k];
+}
+
+// Adjacent-output horizontal pass (ica_kernels.hpp, FusedCols).  The outputs are cut into column blocks of `nb` (even);
+// lane l of block b produces outputs b nb + 2 l and b nb + 2 l + 1 from the `pair_win` input columns that start at
+// c0[b] + 4 (l + hoff[b]).  Possible iff, for every block, a common 4-aligned origin exists (-3 .. +1 groups of 4
+// columns from c0[b]) such that both bands of every pair -- their NONZERO weights: at an image border the stored band is
+// longer than that -- lie inside the pair's window.  True for a decimation by exactly 2 (bands of 26 at 2 o - 12),
+// borders included.  wpair[((b pair_win + j) 64 + l) 2 + q] = weight of window column j for output q of the pair.
+inline bool build_pair_pass(const HostBandOp& h, int nb, const std::vector<int>& c0, int pair_win, std::vector<float>& wpair,
+                            std::vector<int>& hoff) {
+  const int n_out = h.n_out, nbk = (n_out + nb - 1) / nb;
+  if (nb <= 0 || nb % 2 != 0 || nb > 128 || (int)c0.size() != nbk) return false;
+  std::vector<int> f0(n_out), f1(n_out);   // first / last column with a nonzero weight
+  for (int o = 0; o < n_out; ++o) {
+    int a = h.K, b = -1;
+    for (int k = 0; k < h.K; ++k)
+      if (h.w[(size_t)o * h.K + k] != 0.0) { a = std::min(a, k); b = std::max(b, k); }
+    if (b < 0) { a = 0; b = 0; }
+    f0[o] = h.start[o] + a;
+    f1[o] = h.start[o] + b;
+  }
+  wpair.assign((size_t)nbk * pair_win * 64 * 2, 0.0f);
+  hoff.assign(nbk, 0);
+  for (int bx = 0; bx < nbk; ++bx) {
+    const int ob = bx * nb, oe = std::min(ob + nb, n_out);
+    int org = f0[ob];
+    for (int o = ob; o < oe; ++o) org = std::min(org, f0[o] - 4 * ((o - ob) / 2));
+    org = (int)std::floor(org / 4.0) * 4;
+    const int off = (org - c0[bx]) / 4;
+    if ((org - c0[bx]) % 4 != 0 || off < -3 || off > 1) return false;
+    hoff[bx] = off;
+    for (int o = ob; o < oe; ++o) {
+      const int l = (o - ob) / 2, q = (o - ob) & 1, w0 = org + 4 * l;
+      if (f0[o] < w0 || f1[o] > w0 + pair_win - 1) return false;
+      for (int k = 0; k < h.K; ++k) {
+        const int j = h.start[o] + k - w0;
+        if (j >= 0 && j < pair_win) wpair[(((size_t)bx * pair_win + j) * 64 + l) * 2 + q] = (float)h.w[(size_t)o * h.K + k];
+      }
+    }
+  }
+  return true;
+}
+
 // zoom.py:8-22: int(np.round(n * factor)), numpy rounds half to even.
 inline int round_half_even(double v) {
   const double r = std::nearbyint(v);  // default FE_TONEAREST = half to even

@@ -118,6 +118,68 @@ int main() {
   }
   CHECK(round_half_even(2.5) == 2 && round_half_even(3.5) == 4 && round_half_even(67.5) == 68);
 
+  // ---- decimation by 2: bit-identical interior weights, and the adjacent-output pass's per-lane window weights ----
+  const int sizes2[][2] = {{1024, 512}, {512, 256}, {270, 135}, {128, 64}, {96, 48}, {135, 68}, {128, 96}, {300, 100}};
+  for (auto& sz : sizes2) {
+    HostBandOp op = build_rescale_op(sz[0], sz[1]);
+    const HostBandOp before = op;
+    int f = 0, e = 0;
+    std::vector<float> sw;
+    canonicalise_interior(op, 26, f, e, sw);
+    if (sz[0] == 2 * sz[1]) {
+      CHECK(op.K == 26 && f <= 6 && e >= sz[1] - 6 && e > f);
+      for (int o = f; o < e; ++o) {
+        CHECK(op.start[o] == 2 * o - 12);
+        for (int k = 0; k < op.K; ++k) {
+          CHECK(op.w[(size_t)o * op.K + k] == op.w[(size_t)f * op.K + k] && (float)op.w[(size_t)o * op.K + k] == sw[k]);
+          CHECK(std::fabs(op.w[(size_t)o * op.K + k] - before.w[(size_t)o * op.K + k]) <= 1.3e-7);   // only the last bits moved
+        }
+      }
+    } else {
+      CHECK(f == e);
+      CHECK(op.w == before.w);
+    }
+    // column blocks as get_op() cuts them: the largest multiple of 8 outputs whose bands fit 256 columns from a 4-aligned start
+    const int n_out = sz[1];
+    auto fits = [&](int nb) {
+      for (int ob = 0; ob < n_out; ob += nb)
+        if (op.start[std::min(ob + nb, n_out) - 1] + op.K - (op.start[ob] & ~3) > 256) return false;
+      return true;
+    };
+    int nb = 128;
+    while (nb >= 16 && !fits(nb)) nb -= 8;
+    if (nb < 16) continue;
+    std::vector<int> c0;
+    for (int ob = 0; ob < n_out; ob += nb) c0.push_back(op.start[ob] & ~3);
+    std::vector<float> wp;
+    std::vector<int> off;
+    const bool ok = build_pair_pass(op, nb, c0, 28, wp, off);
+    if (sz[0] == 2 * sz[1]) CHECK(ok);
+    if (!ok) continue;
+    CHECK(wp.size() == c0.size() * 28 * 64 * 2 && off.size() == c0.size());
+    for (int o = 0; o < n_out; ++o) {   // the window weights of an output are its band, nothing else
+      const int bx = o / nb, l = (o - bx * nb) / 2, q = (o - bx * nb) & 1, w0 = c0[bx] + 4 * (off[bx] + l);
+      CHECK(off[bx] >= -3 && off[bx] <= 1);
+      double sum = 0;
+      for (int j = 0; j < 28; ++j) {
+        const float t = wp[(((size_t)bx * 28 + j) * 64 + l) * 2 + q];
+        const int k = w0 + j - op.start[o];
+        const float want = (k >= 0 && k < op.K) ? (float)op.w[(size_t)o * op.K + k] : 0.0f;
+        CHECK(t == want);
+        sum += t;
+      }
+      double full = 0;
+      for (int k = 0; k < op.K; ++k) full += (float)op.w[(size_t)o * op.K + k];
+      CHECK(std::fabs(sum - full) < 1e-12);   // no band weight fell outside the window
+    }
+    // lanes past a block's last output carry no weights
+    for (size_t bx = 0; bx < c0.size(); ++bx) {
+      const int outs = std::min(nb, n_out - (int)bx * nb);
+      for (int l = (outs + 1) / 2; l < 64; ++l)
+        for (int j = 0; j < 28; ++j) CHECK(wp[((bx * 28 + j) * 64 + l) * 2] == 0.0f && wp[((bx * 28 + j) * 64 + l) * 2 + 1] == 0.0f);
+    }
+  }
+
   // ---- LU inverse (np.linalg.inv semantics) ----
   unsigned seed = 12345u;
   for (int n : {2, 3, 4, 6, 8}) {
