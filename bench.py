@@ -79,7 +79,7 @@ def library_fingerprint():
         return None
 
 
-def measured_traffic(cfg):
+def measured_traffic(cfg, storage="f32"):
     """HBM bytes / algorithmic bytes of one full-batch launch of this workload's iteration kernel, from the committed
     PMC passes (profiles/r03_traffic.json, built by tools/pmc_traffic.sh from rocprofv3 --pmc FETCH_SIZE CSVs; x1024 B,
     x2 gfx950 correction).  bench.py cannot collect PMC counters itself: the per-launch `traffic` it reports is this
@@ -91,7 +91,8 @@ def measured_traffic(cfg):
             doc = json.load(fh)
         if not doc.get("library_fingerprint") or doc["library_fingerprint"] != library_fingerprint():
             return None, f"stale: {os.path.basename(TRAFFIC_FILE)} was measured on another build of the library"
-        e = doc["kernels"][kernel_key(cfg)]
+        # (the uint8-storage instantiation is a kernel of its own: its counters, or nothing)
+        e = doc["kernels"][kernel_key(cfg) + (" u8" if storage == "u8" else "")]
         return float(e["fetch_bytes_over_algorithmic_bytes"]), e.get("source")
     except Exception:
         return None, None
@@ -410,7 +411,7 @@ def measure(args, info, sharding, cfg_id, steps, warmup, D, batch=0, storage="f3
                                "every launch, one sample per event-bracketed step of the timed region"}
                     if cs else None)
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    ratio, src = measured_traffic(cfg)
+    ratio, src = measured_traffic(cfg, storage)
     out = dict(
         cfg=cfg, dt=dt, units_all=units_all, pairs_all=pairs_all, ms_per_step=ms_per_step,
         step_latency_ms=acc["latency"] / max(steps, 1) * 1e3, gen_seconds=t_gen,

@@ -22,6 +22,7 @@ def test_traffic_is_null_unless_measured_on_the_loaded_library(tmp_path, monkeyp
     monkeypatch.setattr(bench, "TRAFFIC_FILE", str(f))
     monkeypatch.setattr(bench, "library_fingerprint", lambda: "abc")
     assert bench.measured_traffic(cfg) == (1.12, "somewhere")
+    assert bench.measured_traffic(cfg, "u8")[0] is None                # the uint8-storage kernel was not measured: no figure
     monkeypatch.setattr(bench, "library_fingerprint", lambda: "another build")
     ratio, why = bench.measured_traffic(cfg)
     assert ratio is None and "stale" in why
