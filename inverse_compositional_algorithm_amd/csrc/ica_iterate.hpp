@@ -1,14 +1,15 @@
-// Fused per-iteration pass, LDS-staged + double-buffered (the production kernel).
+// Fused per-iteration pass, LDS-staged (the production kernel).
 //
 // One workgroup (4 waves) owns a 64-column x tile_h-row tile of one image pair and walks it in chunks of
-// CH rows.  For every chunk:
+// CH rows (32 for one channel, 16 for three).  For every chunk:
 //   1. The footprint of the chunk under the current warp is the convex quadrilateral of its 4 mapped
 //      corners; its bounding box (+ bicubic halo) of I2 and the chunk (+1-px halo) of I1 are moved
-//      HBM/L2 -> LDS by LDS-DMA (buffer_load ... lds, 16 B per lane, no VGPRs).  The copy for chunk k+1 is issued
-//      right after the barrier that publishes chunk k, so it runs underneath chunk k's arithmetic
-//      (two LDS buffers, one barrier per chunk).  A footprint that does not fit the buffer falls back to
-//      direct cached gathers for that chunk -- same arithmetic, same results.
-//   2. Each lane owns one image column; each wave walks RW consecutive rows.  All 16 bicubic taps and the
+//      HBM/L2 -> LDS by LDS-DMA (buffer_load ... lds, 16 B per lane, no VGPRs) into ONE tile per workgroup: barrier, copy
+//      chunk k, barrier, arithmetic on chunk k -- a workgroup's copy is not hidden behind its own arithmetic, the other
+//      five workgroups of the CU cover it (two tiles with the next chunk copied under the current one were measured
+//      slower, like everything else that trades workgroups per CU for buffering: DESIGN.md 5.1).  A footprint that
+//      does not fit the tile falls back to direct cached gathers for that chunk -- same arithmetic, same results.
+//   2. Each lane owns one image column; each wave walks RW = CH / 4 consecutive rows.  All 16 bicubic taps and the
 //      5-point gradient stencil come from LDS with compile-time offsets; nothing but the two images is ever
 //      read from memory (the reference materialises 192 B/pixel of gradient/Jacobian/steepest-descent tensors).
 //   3. "Moment" accumulation.  Every Jacobian entry is a monomial c*x^a*y^b (derivatives.py:33-68), so
@@ -20,20 +21,23 @@
 //      once per tile, in fp64, when the 64 lanes' moments are folded into the <= 44 sums.
 //   fp32 per pixel, promoted to fp64 at the end of the tile; fixed summation order throughout (deterministic).
 //
-// Two instruction streams per chunk.  The kernel is bound by VALU issue and LDS reads, not by HBM, and on gfx950 the
-// issue cost of a vector instruction depends on its FORM (measured, tools/ubench/issue_cost.hip, 6 waves per SIMD,
-// relative to a VOP2 on registers = 1): VOP3 fma 1.35, anything with an SGPR operand 1.5-2.4, packed fp32 2.3 (for
-// two results), 3-operand integer forms 2.4, DPP / mad24 2.9, v_cndmask on vcc far more.  So:
+// Three instruction streams per chunk.  The kernel is not bound by HBM bytes but by three stations at 60-85 % each -- the
+// L1's line requests for the tile copies, the LDS reads of the taps, vector-instruction issue -- and on
+// gfx950 the issue cost of a vector instruction depends on its FORM (tools/ubench/valu_floor.hip: 2 cycles for VOP2 /
+// VOP3 on registers, inline constants or a literal; 4 with an SGPR operand, for v_floor / v_fract / v_cvt / v_max /
+// v_med3 / shifts and for packed fp32 (two results); 8 for v_rcp / v_rsq; an fp32 MFMA blocks the issue port for its
+// whole duration).  So:
 //   * INTERIOR chunks -- no pixel in the NaN frame or on the gradient border, every bicubic footprint inside I2,
 //     decided once per chunk from the mapped corners (the large majority of a level-0 image) -- run `band_fast`:
-//     no masks, no validity tests, no selects; 4 rows unrolled; every wave-uniform operand (y powers, warp
+//     no masks, no validity tests, no selects; the wave's rows unrolled; every wave-uniform operand (y powers, warp
 //     coefficients, clip range, lambda^2) is kept in a VGPR so the multiply-adds are VOP2 v_fmac on registers; the
-//     robust function is a template argument (no branches in the loop); v_fract + v_cvt_flr instead of
-//     floor/subtract/convert; the Keys weights in their factored form (10 operations per axis instead of 14).
-//   * BORDER chunks run `band_careful`, which keeps every test of the reference's pixel masks, and re-evaluates a
-//     sampling position in float64 when its fp32 value is within 2^-16 of an integer: there floor() decides whether a
-//     border pixel's 4x4 footprint counts as inside the image (bicubic_interpolation.py:199, cval=nan), and fp32 and
-//     the reference's float64 could otherwise part ways.
+//     robust function is a template argument (no branches in the loop); the tap address formed in fp32 (exact small
+//     integers); the Keys weights in their factored form (9 operations per axis).
+//   * MASKED-border chunks (one channel) run the same stream with the frame pixels' residual and weight selected to 0.
+//   * The remaining BORDER chunks run `band_careful`, which keeps every test of the reference's pixel masks, and
+//     re-evaluates a sampling position in float64 when its fp32 value is within 2^-16 of an integer: there floor()
+//     decides whether a border pixel's 4x4 footprint counts as inside the image (bicubic_interpolation.py:199,
+//     cval=nan), and fp32 and the reference's float64 could otherwise part ways.
 #pragma once
 #include <type_traits>
 
