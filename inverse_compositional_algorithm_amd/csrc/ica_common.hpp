@@ -31,9 +31,16 @@ namespace ica {
 #ifndef ICA_CH3    // image rows per chunk, three channels (three RESIDENT channels only fit the LDS as 16-row chunks)
 #define ICA_CH3 (ICA_CSEQ ? 32 : 16)
 #endif
+#ifndef ICA_DUP    // 1 (an experiment): one-channel float32 tiles hold a second copy of the I2 footprint, shifted by one float, so that
+#define ICA_DUP 0  // every pair of adjacent taps is an aligned 8-byte LDS read (ica_iterate.hpp, TileCfg::dup); 24-row chunks, 5 waves
+#endif
+#ifndef ICA_CH_DUP
+#define ICA_CH_DUP 24
+#endif
 // rows per chunk of the kernel that runs a level of `channels` channels stored as uint8 (`u8`) or float32
 constexpr int iter_chunk_rows(int channels, bool u8) {
-  return (ICA_LOADER != 0 && channels == 1 && !u8) ? ICA_CH_LOADER : channels == 1 ? ICA_CH : ICA_CH3;
+  return (ICA_LOADER != 0 && channels == 1 && !u8) ? ICA_CH_LOADER
+         : (ICA_DUP != 0 && channels == 1 && !u8) ? ICA_CH_DUP : channels == 1 ? ICA_CH : ICA_CH3;
 }
 
 constexpr int kBlock = 256;   // 4 waves

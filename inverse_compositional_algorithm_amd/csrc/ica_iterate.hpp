@@ -143,7 +143,7 @@ template <int TT> struct MomLayout {
   static constexpr int maxpow = 2 * mby > 2 * mbx ? 2 * mby : 2 * mbx;  // highest y power any moment needs
 };
 
-template <int C, bool LOADER = false> struct TileCfg {
+template <int C, bool LOADER = false, bool DUP = false> struct TileCfg {
   // Image rows per chunk: 4 waves x ch/4 rows.  One channel: 32 rows in ONE 22.9 KB tile (6 workgroups per CU), copy and
   // arithmetic of a workgroup alternate and the other five overlap them.  Measured against 16-row chunks in two tiles
   // (chunk k+1 copied under chunk k's arithmetic, 26.4 KB): 3-7 % faster on every one-channel kernel -- half the
@@ -163,13 +163,14 @@ template <int C, bool LOADER = false> struct TileCfg {
   // bound by (57 dwords per pixel row).
   static constexpr bool seq = (C == 3) && (ICA_CSEQ != 0);
   static constexpr int lc = seq ? 1 : C;               // channels resident in the tile
-  static constexpr int ch = LOADER ? ICA_CH_LOADER : (C == 1) ? ICA_CH : ICA_CH3;
+  static constexpr bool dup = DUP;                     // a second, one-float-shifted copy of the I2 footprint (ICA_DUP)
+  static constexpr int ch = LOADER ? ICA_CH_LOADER : DUP ? ICA_CH_DUP : (C == 1) ? ICA_CH : ICA_CH3;
   static constexpr int rw = ch / compute_waves(C);
   static_assert(ch % compute_waves(C) == 0, "a chunk is split evenly among the computing waves");
   static constexpr int p2 = 80, r2 = ch + 9;           // I2 footprint buffer: pitch (floats) x rows
   static constexpr int p1 = 72, r1 = ch + 2;           // I1 buffer: columns x_t0-4 .. x_t0+67, rows yc0-1 .. yc0+ch
   static constexpr int nbuf = LOADER ? 2 : (C == 1) ? ICA_NBUF : 1;
-  static constexpr int buf_floats = lc * (p2 * r2 + p1 * r1);
+  static constexpr int buf_floats = lc * (p2 * r2 + p1 * r1) + (DUP ? p2 * r2 : 0);
 };
 
 // 4 bytes per lane, global -> LDS at (wave-uniform) lds_base + 4*lane: rows that are not 16-byte aligned
@@ -305,7 +306,7 @@ __device__ __forceinline__ float rho_prime_t(float t2, float lam2) {
 // workgroup: barrier, expand chunk k, barrier, start the copy of chunk k+1, compute chunk k.
 template <int TT, int MODE, int C, int RT, bool U8>
 // (second launch bound = waves per SIMD the register allocator must leave room for: what the LDS footprint allows)
-__global__ __launch_bounds__((IterCfg<C, U8>::block), (IterCfg<C, U8>::loader ? (IterCfg<C, U8>::waves * 4 + 3) / 4 : C == 1 ? (U8 ? ICA_ITER_WAVES_U8 : ICA_ITER_WAVES) : U8 ? 3 : 4)) void ica_iterate_kernel(LevelArgs a) {
+__global__ __launch_bounds__((IterCfg<C, U8>::block), (IterCfg<C, U8>::loader ? (IterCfg<C, U8>::waves * 4 + 3) / 4 : C == 1 ? (U8 ? ICA_ITER_WAVES_U8 : ICA_DUP ? 5 : ICA_ITER_WAVES) : U8 ? 3 : 4)) void ica_iterate_kernel(LevelArgs a) {
   using WG = IterCfg<C, U8>;
   constexpr bool kLoader = WG::loader;
   constexpr int kIterWaves = WG::waves, kIterBlock = WG::block, kCopyWaves = WG::copy_waves, kComputeWaves = WG::cw;
@@ -318,7 +319,9 @@ __global__ __launch_bounds__((IterCfg<C, U8>::block), (IterCfg<C, U8>::loader ? 
   constexpr bool kProj = (TT == ICA_HOMOGRAPHY);
   constexpr bool kRobust = (MODE == kModeRobust);
   using ML = MomLayout<TT>;
-  using TC = TileCfg<C, kLoader>;
+  constexpr bool kDup = (ICA_DUP != 0) && C == 1 && !U8 && !kLoader;
+  using TC = TileCfg<C, kLoader, kDup>;
+  constexpr int kI2Copies = kDup ? 2 : 1;   // footprint copies in front of the I1 tile
   constexpr int CH = TC::ch, RW = TC::rw, P2 = TC::p2, R2 = TC::r2, P1 = TC::p1, R1 = TC::r1;
   constexpr bool kSeq = TC::seq;                          // one channel in the tile at a time (see TileCfg)
   constexpr int LC = TC::lc, kPasses = kSeq ? C : 1;
@@ -558,7 +561,7 @@ __global__ __launch_bounds__((IterCfg<C, U8>::block), (IterCfg<C, U8>::loader ? 
     const int px = plan_px(k), y_lo = plan_ylo(k);
     // destination: the float tile `buf`, or (U8) the staging area behind the tile, laid out like the tile, in bytes
     TIn* b2 = U8 ? reinterpret_cast<TIn*>(lds + NBUF * TC::buf_floats) : reinterpret_cast<TIn*>(lds + buf * TC::buf_floats);
-    TIn* b1 = b2 + LC * P2 * R2;
+    TIn* b1 = b2 + LC * kI2Copies * P2 * R2;
     const int yc0 = y_begin + k * CH;
     [[maybe_unused]] const unsigned pass_off = kSeq ? (unsigned)((size_t)pass * plane * ES) : 0u;
     if (w4) {
@@ -604,6 +607,8 @@ __global__ __launch_bounds__((IterCfg<C, U8>::block), (IterCfg<C, U8>::loader ? 
 #pragma unroll
             for (int c = 0; c < LC; ++c)
               ICA_LDS_DMA(U8, rs2, dst + c * P2 * R2, o + pass_off + (unsigned)(c * plane * ES));
+            // second copy, one float to the left (B[j] = A[j + 1]): an odd tap address in A is an even one in B
+            if constexpr (kDup) ICA_LDS_DMA(U8, rs2, dst + P2 * R2, o + 4u);
           }
         }
       }
@@ -631,6 +636,10 @@ __global__ __launch_bounds__((IterCfg<C, U8>::block), (IterCfg<C, U8>::loader ? 
             float* dst = b2 + c * P2 * R2 + r * P2;
             if (x_lo + lane < W) glds4(src + lane, dst);
             if ((lane < P2 - 64) & (x_lo + 64 + lane < W)) glds4(src + 64 + lane, dst + 64);
+            if constexpr (kDup) {
+              if (x_lo + 1 + lane < W) glds4(src + 1 + lane, dst + P2 * R2);
+              if ((lane < P2 - 64) & (x_lo + 65 + lane < W)) glds4(src + 65 + lane, dst + P2 * R2 + 64);
+            }
           }
         }
       }
@@ -868,7 +877,7 @@ __global__ __launch_bounds__((IterCfg<C, U8>::block), (IterCfg<C, U8>::loader ? 
     [[maybe_unused]] const bool staged = (px & (1 << 30)) != 0;
     const int x_lo = px & 0xFFFFF;
     const float* b2 = lds + buf * TC::buf_floats;
-    const float* b1 = b2 + LC * P2 * R2;
+    const float* b1 = b2 + LC * kI2Copies * P2 * R2;
     const int yc0 = y_begin + k * CH;
     const int yb0 = yc0 + wave * RW;
     const float* i1p = b1 + (wave * RW) * P1 + lane + 4;  // row yb0-1 of this lane's column
@@ -1072,6 +1081,24 @@ __global__ __launch_bounds__((IterCfg<C, U8>::block), (IterCfg<C, U8>::loader ? 
           } else {
           keys_weights(fx, wx);
           keys_weights(fy, wy);
+          if constexpr (kDup) {
+            // an odd tap (0,0) address: the same four floats start one float earlier -- 8-byte aligned -- in the second copy
+            const unsigned odd = addr & 4u;
+            const unsigned a2 = (unsigned)__umul24(odd, (unsigned)((P2 * R2 * 4 - 4) / 4)) + addr;
+            const __attribute__((address_space(3))) ica_f2* q2 = (const __attribute__((address_space(3))) ica_f2*)(uintptr_t)a2;
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const ica_f2 t01 = q2[r * (P2 / 2)], t23 = q2[r * (P2 / 2) + 1];
+              float s = wx[0] * t01.x;
+              s = __builtin_fmaf(wx[1], t01.y, s);
+              s = __builtin_fmaf(wx[2], t23.x, s);
+              s = __builtin_fmaf(wx[3], t23.y, s);
+              v = (r == 0) ? wy[0] * s : __builtin_fmaf(wy[r], s, v);
+            }
+            di[0] = __builtin_amdgcn_fmed3f(v, lo, hi_v) - cm[0];  // clip (skimage warp), ref :114
+            if constexpr (MASKED) di[0] = live ? di[0] : 0.0f;
+          } else
 #pragma unroll
           for (int c = 0; c < C; ++c) {
             const __attribute__((address_space(3))) float* q =
