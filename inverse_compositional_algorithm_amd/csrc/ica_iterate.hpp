@@ -181,13 +181,20 @@ __device__ __forceinline__ void glds4(const float* gsrc, float* lds_base) {
 
 // one LDS-DMA instruction: 4 (uint8 storage) or 16 (float32) bytes per lane from descriptor `rs` at byte offset `off`
 // to LDS `dst` + bytes * lane.  (The size operand of the builtin must be a literal.)
-#define ICA_LDS_DMA(U8, rs, dst, off)                                                                                 \
+#ifndef ICA_DMA_AUX1   // cache policy bits of the I1 / I2 tile copies (0: default, 2: nt, 1: sc0, 16: sc1) -- experiment hooks
+#define ICA_DMA_AUX1 0
+#endif
+#ifndef ICA_DMA_AUX2
+#define ICA_DMA_AUX2 0
+#endif
+#define ICA_LDS_DMA_AUX(U8, rs, dst, off, AUX)                                                                        \
   do {                                                                                                                \
     if constexpr (U8)                                                                                                 \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst), 4, (int)(off), 0, 0, 0); \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst), 4, (int)(off), 0, 0, AUX); \
     else                                                                                                              \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst), 16, (int)(off), 0, 0, 0); \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst), 16, (int)(off), 0, 0, AUX); \
   } while (0)
+#define ICA_LDS_DMA(U8, rs, dst, off) ICA_LDS_DMA_AUX(U8, rs, dst, off, 0)
 
 // A wave-uniform value the compiler would keep in an SGPR (a VALU operand read from an SGPR costs 1.5-2.4x the
 // issue time of the same instruction on a VGPR, see the header): pin it to a VGPR.
@@ -582,7 +589,7 @@ __global__ __launch_bounds__((IterCfg<C, U8>::block), (IterCfg<C, U8>::loader ? 
           const unsigned o = off1 + u;  // a poisoned offset stays out of range
 #pragma unroll
           for (int c = 0; c < LC; ++c)
-            ICA_LDS_DMA(U8, rs1, dst + c * P1 * R1, o + pass_off + (unsigned)(c * plane * ES));
+            ICA_LDS_DMA_AUX(U8, rs1, dst + c * P1 * R1, o + pass_off + (unsigned)(c * plane * ES), ICA_DMA_AUX1);
         }
       }
       if constexpr (kB) {
@@ -606,7 +613,7 @@ __global__ __launch_bounds__((IterCfg<C, U8>::block), (IterCfg<C, U8>::loader ? 
             const unsigned o = off2 + u;  // all P2 columns of a row are copied (a few more than needed)
 #pragma unroll
             for (int c = 0; c < LC; ++c)
-              ICA_LDS_DMA(U8, rs2, dst + c * P2 * R2, o + pass_off + (unsigned)(c * plane * ES));
+              ICA_LDS_DMA_AUX(U8, rs2, dst + c * P2 * R2, o + pass_off + (unsigned)(c * plane * ES), ICA_DMA_AUX2);
             // second copy, one float to the left (B[j] = A[j + 1]): an odd tap address in A is an even one in B
             if constexpr (kDup) ICA_LDS_DMA(U8, rs2, dst + P2 * R2, o + 4u);
           }
