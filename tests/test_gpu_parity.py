@@ -322,6 +322,25 @@ def test_full_solve_matches_oracle(eng, t, r, ns, C):
     assert res.stats["pair_iterations_total"] == total
 
 
+def test_profiling_reports_kernel_time_and_the_clock_the_kernel_ran_at(eng):
+    """ica_set_profiling: HIP-event time of the iteration kernel's launches and ica_stats.shader_clock_ghz, measured inside the
+    kernel (one workgroup's lifetime in shader cycles over the same in 100 MHz ticks); both zero with profiling off."""
+    t = oc.HOMOGRAPHY
+    I1s, I2s, _ = pairs(t, 8, H=256, W=320, C=1, clutter=True, seed0=4100)
+    prob = eng.problem(8, 256, 320, 1, t, oc.LORENTZIAN, nscales=2, delta=5)
+    a, b = to_dev(eng, *I1s), to_dev(eng, *I2s)
+    try:
+        eng.set_profiling(True)
+        on = eng.solve(a, b, prob, want_stats=True)
+    finally:
+        eng.set_profiling(False)
+    off = eng.solve(a, b, prob, want_stats=True)
+    assert torch.equal(on.p, off.p) and torch.equal(on.niter, off.niter)      # measuring changes nothing
+    assert 0.8 < on.stats["shader_clock_ghz"] < 2.6, on.stats["shader_clock_ghz"]
+    assert sum(on.stats["iter_kernel_ms"]) > 0.0
+    assert off.stats["shader_clock_ghz"] == 0.0 and sum(off.stats["iter_kernel_ms"]) == 0.0
+
+
 def test_initial_p_used_only_for_single_scale(eng):
     """ref :327,:337,:372 -- with nscales > 1 the caller's p is discarded."""
     t = oc.AFFINITY
