@@ -562,7 +562,7 @@ __global__ __launch_bounds__((IterCfg<C, U8>::block), (IterCfg<C, U8>::loader ? 
   //  the move and its dependency sit in front of the copies.  profiles/r02_ablation.txt)
   const bool copies = !kLoader || wave >= kComputeWaves;   // (with loader waves: they alone copy)
   auto issue_impl = [&](int k, int buf, int pass) {   // pass: the channel to copy (channel-sequential tiles only)
-#if defined(ICA_ABLATE) && (ICA_ABLATE & 2)   // (ICA_ABLATE is a set of bits: 1 copies only, 2 no copies, 4 lane-linear taps, 8 no barriers, 16 half the tap reads, 64 no Hessian moments)
+#if defined(ICA_ABLATE) && (ICA_ABLATE & 2)   // (ICA_ABLATE is a set of bits: 1 copies only, 2 no copies, 4 lane-linear taps, 8 no barriers, 16 half the tap reads, 64 no Hessian moments, 128 no I1 copies, 256 no I2 copies)
     return;  // timing-only build: no LDS-DMA
 #endif
     const int px = plan_px(k), y_lo = plan_ylo(k);
@@ -576,6 +576,9 @@ __global__ __launch_bounds__((IterCfg<C, U8>::block), (IterCfg<C, U8>::loader ? 
       const bool skip = (px & (1 << 29)) != 0;
       // may wrap below 0 (row -1): then out of range.  A skipped chunk gets an out-of-range base.
       const unsigned base1 = skip ? 0x40000000u : (unsigned)(((yc0 - 1) * W + x_t0) * ES);
+#if defined(ICA_ABLATE) && (ICA_ABLATE & 128)   // timing-only build: no I1 copies
+      if (false)
+#endif
 #pragma unroll
       for (int qq = 0; qq < (NQ1 + kCopyWaves - 1) / kCopyWaves; ++qq) {
         const int q = (kLoader ? wave - kComputeWaves : wave) + qq * kCopyWaves;      // this wave's row group (wave-uniform)
@@ -592,7 +595,11 @@ __global__ __launch_bounds__((IterCfg<C, U8>::block), (IterCfg<C, U8>::loader ? 
             ICA_LDS_DMA_AUX(U8, rs1, dst + c * P1 * R1, o + pass_off + (unsigned)(c * plane * ES), ICA_DMA_AUX1);
         }
       }
+#if defined(ICA_ABLATE) && (ICA_ABLATE & 256)   // timing-only build: no I2 copies
+      if constexpr (false) {
+#else
       if constexpr (kB) {
+#endif
         const bool stage = !skip && (px & (1 << 30));
         const int x_lo = px & 0xFFFFF;
         const int bh = stage ? plan_bh(k) : 0;
