@@ -545,10 +545,7 @@ __global__ __launch_bounds__((IterCfg<C, U8>::block), (IterCfg<C, U8>::loader ? 
   // row, row shift, how many rows) is wave-uniform.  The tile's row groups are dealt round-robin to the 4 waves.
   const auto rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)I1, 0, (int)(C * plane * ES), 0x00020000);
   constexpr int V1 = P1 / 4, V2 = P2 / 4;                       // float4 per buffer row
-#ifndef ICA_RPMAX   // experiment hook: at most this many tile rows per copy instruction (3 fit; fewer = more instructions, same bytes)
-#define ICA_RPMAX 8
-#endif
-  constexpr int RP1 = (64 / V1 < ICA_RPMAX ? 64 / V1 : ICA_RPMAX), RP2 = (64 / V2 < ICA_RPMAX ? 64 / V2 : ICA_RPMAX);   // rows per wave-instruction
+  constexpr int RP1 = 64 / V1, RP2 = 64 / V2;                   // rows per wave-instruction
   constexpr int NQ1 = (R1 + RP1 - 1) / RP1, NQ2 = (R2 + RP2 - 1) / RP2;  // row groups per tile
   constexpr unsigned kPoison = 0x80000000u;                     // offset that is always out of range
   unsigned off1, off2;
